@@ -1,0 +1,353 @@
+// Streaming map kernel for gfx950: every thermo entry point is one launch of
+// this template over an Op from ops.hpp.
+//
+// Data movement (the part that decides performance; the path is HBM-bound):
+//  * 16 B per lane per access (float4 / double2): one wave = 1 KiB per
+//    global_load_dwordx4 / global_store_dwordx4, fully coalesced;
+//  * every input field is read once, every output field written once;
+//  * loads/stores are non-temporal: nothing is re-used, so the streams should
+//    not displace each other in L2 / MALL;
+//  * persistent grid (CUs x blocks_per_cu workgroups) with a grid-stride loop,
+//    UNROLL independent vectors per lane per trip to keep >= 32 KiB of loads in
+//    flight per CU;
+//  * operands that are not full fields (a scalar, or a level vector such as the
+//    137 model-level pressures) never touch HBM per point: the vector is staged
+//    once per workgroup into LDS and indexed by level, with the level index
+//    advanced incrementally (no per-point integer division).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/ekm_thermo.h"
+#include "ops.hpp"
+
+namespace ekm {
+
+constexpr int kThreads = 256;
+
+template <class T>
+struct VecOf;
+template <>
+struct VecOf<float> {
+  typedef float type __attribute__((ext_vector_type(4)));
+  static constexpr int N = 4;
+};
+template <>
+struct VecOf<double> {
+  typedef double type __attribute__((ext_vector_type(2)));
+  static constexpr int N = 2;
+};
+
+template <class T, int NIN, int NOUT>
+struct MapArgs {
+  const T* in[NIN];
+  T* out[NOUT];
+  unsigned long long n;
+  T rp;
+  // broadcast description (used by the BC instantiation only)
+  int mode[NIN];                 // EKM_FIELD / EKM_SCALAR / EKM_LEVEL_MAJOR / EKM_LEVEL_MINOR
+  unsigned len[NIN];             // vector length for the LEVEL modes
+  unsigned lds_off[NIN];         // element offset of the staged vector in LDS
+  unsigned long long inner[NIN]; // LEVEL_MAJOR: points per level
+  unsigned long long step_q[NIN];  // (grid stride in elements) / inner   resp. unused
+  unsigned long long step_r[NIN];  // (grid stride in elements) % inner   resp. % len
+  int vec_ok;                    // all field pointers 16-B aligned
+};
+
+template <class T>
+__device__ __forceinline__ typename VecOf<T>::type ld_stream(const T* p) {
+  typedef typename VecOf<T>::type V;
+  return __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+}
+
+template <class T>
+__device__ __forceinline__ void st_stream(T* p, typename VecOf<T>::type v) {
+  typedef typename VecOf<T>::type V;
+  __builtin_nontemporal_store(v, reinterpret_cast<V*>(p));
+}
+
+// ---- all operands are aligned full fields ----------------------------------
+template <class Op, class T, int UNROLL>
+__global__ __launch_bounds__(kThreads) void map_fields(const MapArgs<T, Op::NIN, Op::NOUT> a) {
+  constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N;
+  typedef typename VecOf<T>::type Vec;
+  const unsigned long long nvec = a.n / V;
+  const unsigned long long stride = (unsigned long long)gridDim.x * kThreads;
+  unsigned long long v = (unsigned long long)blockIdx.x * kThreads + threadIdx.x;
+
+  for (; v + (UNROLL - 1) * stride < nvec; v += UNROLL * stride) {
+    Vec xin[UNROLL][NIN];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+      for (int i = 0; i < NIN; ++i) xin[u][i] = ld_stream<T>(a.in[i] + (v + u * stride) * V);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      Vec yout[NOUT];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        T x[NIN], y[NOUT];
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) x[i] = xin[u][i][j];
+        Op::template apply<T>(x, y, a.rp);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) yout[o][j] = y[o];
+      }
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) st_stream<T>(a.out[o] + (v + u * stride) * V, yout[o]);
+    }
+  }
+  // remaining whole vectors (fewer than UNROLL per lane)
+  for (; v < nvec; v += stride) {
+    Vec xin[NIN], yout[NOUT];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) xin[i] = ld_stream<T>(a.in[i] + v * V);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      T x[NIN], y[NOUT];
+#pragma unroll
+      for (int i = 0; i < NIN; ++i) x[i] = xin[i][j];
+      Op::template apply<T>(x, y, a.rp);
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) yout[o][j] = y[o];
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) st_stream<T>(a.out[o] + v * V, yout[o]);
+  }
+  // ragged tail: n % V single elements
+  const unsigned long long e = nvec * V + (unsigned long long)blockIdx.x * kThreads + threadIdx.x;
+  if (e < a.n) {
+    T x[NIN], y[NOUT];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) x[i] = a.in[i][e];
+    Op::template apply<T>(x, y, a.rp);
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) a.out[o][e] = y[o];
+  }
+}
+
+// ---- some operands are scalars / level vectors (or pointers are unaligned) ---
+extern __shared__ __align__(16) unsigned char ekm_lds_raw[];
+
+template <class Op, class T>
+__global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, Op::NOUT> a) {
+  constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N;
+  typedef typename VecOf<T>::type Vec;
+  T* lds = reinterpret_cast<T*>(ekm_lds_raw);
+
+  // stage the shared vectors once per workgroup
+  T sval[NIN];
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) {
+    sval[i] = T(0);
+    if (a.mode[i] == EKM_SCALAR) sval[i] = a.in[i][0];
+    if (a.mode[i] >= EKM_LEVEL_MAJOR)
+      for (unsigned s = threadIdx.x; s < a.len[i]; s += kThreads) lds[a.lds_off[i] + s] = a.in[i][s];
+  }
+  __syncthreads();
+
+  const unsigned long long nchunk = (a.n + V - 1) / V;  // last chunk may be partial
+  const unsigned long long stride = (unsigned long long)gridDim.x * kThreads;
+  unsigned long long c = (unsigned long long)blockIdx.x * kThreads + threadIdx.x;
+
+  // per-operand running position of element c*V: (level, offset in level) or index
+  unsigned long long pos_q[NIN], pos_r[NIN];
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) {
+    pos_q[i] = 0;
+    pos_r[i] = 0;
+    if (a.mode[i] == EKM_LEVEL_MAJOR) {
+      pos_q[i] = (c * V) / a.inner[i];
+      pos_r[i] = (c * V) % a.inner[i];
+    } else if (a.mode[i] == EKM_LEVEL_MINOR) {
+      pos_r[i] = (c * V) % a.len[i];
+    }
+  }
+
+  for (; c < nchunk; c += stride) {
+    const unsigned long long e0 = c * V;
+    const bool full = (e0 + V <= a.n);
+    Vec xin[NIN];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      if (a.mode[i] == EKM_FIELD) {
+        if (full && a.vec_ok) {
+          xin[i] = ld_stream<T>(a.in[i] + e0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) xin[i][j] = (e0 + j < a.n) ? a.in[i][e0 + j] : T(1);
+        }
+      } else if (a.mode[i] == EKM_SCALAR) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) xin[i][j] = sval[i];
+      } else if (a.mode[i] == EKM_LEVEL_MAJOR) {
+        const T* tab = lds + a.lds_off[i];
+        const unsigned long long l = pos_q[i], r = pos_r[i], inn = a.inner[i];
+        const T v0 = tab[l];
+        if (r + V <= inn) {  // whole chunk inside one level (the usual case)
+#pragma unroll
+          for (int j = 0; j < V; ++j) xin[i][j] = v0;
+        } else {
+          const unsigned last = a.len[i] - 1;
+          const unsigned l1 = (l + 1 <= last) ? (unsigned)(l + 1) : last;
+          const T v1 = tab[l1];  // inner >= V (host-checked): at most one boundary per chunk
+#pragma unroll
+          for (int j = 0; j < V; ++j) xin[i][j] = (r + j < inn) ? v0 : v1;
+        }
+      } else {  // EKM_LEVEL_MINOR, len >= V (host-checked)
+        const T* tab = lds + a.lds_off[i];
+        const unsigned len = a.len[i];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          unsigned idx = (unsigned)pos_r[i] + j;
+          if (idx >= len) idx -= len;
+          xin[i][j] = tab[idx];
+        }
+      }
+    }
+    Vec yout[NOUT];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      T x[NIN], y[NOUT];
+#pragma unroll
+      for (int i = 0; i < NIN; ++i) x[i] = xin[i][j];
+      Op::template apply<T>(x, y, a.rp);
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) yout[o][j] = y[o];
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      if (full && a.vec_ok) {
+        st_stream<T>(a.out[o] + e0, yout[o]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+          if (e0 + j < a.n) a.out[o][e0 + j] = yout[o][j];
+      }
+    }
+    // advance the running positions by one grid stride
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      if (a.mode[i] == EKM_LEVEL_MAJOR) {
+        pos_q[i] += a.step_q[i];
+        pos_r[i] += a.step_r[i];
+        if (pos_r[i] >= a.inner[i]) {
+          pos_r[i] -= a.inner[i];
+          pos_q[i] += 1;
+        }
+      } else if (a.mode[i] == EKM_LEVEL_MINOR) {
+        pos_r[i] += a.step_r[i];
+        if (pos_r[i] >= a.len[i]) pos_r[i] -= a.len[i];
+      }
+    }
+  }
+}
+
+// ---- host side ----------------------------------------------------------------
+int set_error(int code, const char* fmt, ...);
+int device_cus(int dev);            // CU count of device `dev` (cached), <0 on error
+int use_device(int dev);            // hipSetDevice with error capture
+int tuning_blocks_per_cu();
+int tuning_unroll();
+
+constexpr unsigned kMaxLdsBytes = 64 * 1024;
+
+template <class Op, class T>
+int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const* outs, size_t n, double rp) {
+  constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N;
+  if (n == 0) return EKM_OK;
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  const int cus = device_cus(dev);
+  if (cus <= 0) return cus;
+
+  MapArgs<T, NIN, NOUT> a;
+  a.n = n;
+  a.rp = T(rp);
+  bool bc = false, aligned = true;
+  unsigned lds_elems = 0;
+  for (int i = 0; i < NIN; ++i) {
+    const ekm_operand* op = ins[i];
+    if (!op || !op->data) return set_error(EKM_ERR_ARG, "operand %d: null pointer", i);
+    a.in[i] = static_cast<const T*>(op->data);
+    a.mode[i] = op->mode;
+    a.len[i] = 0;
+    a.lds_off[i] = 0;
+    a.inner[i] = 1;
+    a.step_q[i] = a.step_r[i] = 0;
+    switch (op->mode) {
+      case EKM_FIELD:
+        if (reinterpret_cast<uintptr_t>(op->data) % 16) aligned = false;
+        break;
+      case EKM_SCALAR:
+        bc = true;
+        break;
+      case EKM_LEVEL_MAJOR:
+      case EKM_LEVEL_MINOR: {
+        bc = true;
+        if (op->len == 0 || op->len > 0xffffffffull)
+          return set_error(EKM_ERR_ARG, "operand %d: level vector length %llu out of range", i,
+                           (unsigned long long)op->len);
+        a.len[i] = (unsigned)op->len;
+        a.lds_off[i] = lds_elems;
+        lds_elems += (a.len[i] + 3u) & ~3u;
+        if (op->mode == EKM_LEVEL_MAJOR) {
+          if (op->inner < (unsigned)V)
+            return set_error(EKM_ERR_ARG, "operand %d: LEVEL_MAJOR needs inner >= %d (got %llu)", i, V,
+                             (unsigned long long)op->inner);
+          if ((unsigned long long)op->len * op->inner < n)
+            return set_error(EKM_ERR_ARG, "operand %d: len*inner = %llu does not cover n = %llu", i,
+                             (unsigned long long)op->len * op->inner, (unsigned long long)n);
+          a.inner[i] = op->inner;
+        } else if (op->len < (unsigned)V) {
+          return set_error(EKM_ERR_ARG, "operand %d: LEVEL_MINOR needs len >= %d (got %llu)", i, V,
+                           (unsigned long long)op->len);
+        }
+        break;
+      }
+      default:
+        return set_error(EKM_ERR_ARG, "operand %d: unknown mode %d", i, op->mode);
+    }
+  }
+  for (int o = 0; o < NOUT; ++o) {
+    if (!outs[o]) return set_error(EKM_ERR_ARG, "output %d: null pointer", o);
+    a.out[o] = static_cast<T*>(outs[o]);
+    if (reinterpret_cast<uintptr_t>(outs[o]) % 16) aligned = false;
+  }
+  a.vec_ok = aligned ? 1 : 0;
+  if ((size_t)lds_elems * sizeof(T) > kMaxLdsBytes)
+    return set_error(EKM_ERR_ARG, "level vectors need %zu B of LDS (max %u)", (size_t)lds_elems * sizeof(T),
+                     kMaxLdsBytes);
+
+  const unsigned long long nchunk = (n + V - 1) / V;
+  const unsigned long long want = (nchunk + kThreads - 1) / kThreads;
+  const unsigned long long cap = (unsigned long long)cus * tuning_blocks_per_cu();
+  const unsigned grid = (unsigned)(want < cap ? want : cap);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+
+  if (!bc && aligned) {
+    if (tuning_unroll() >= 2)
+      hipLaunchKernelGGL((map_fields<Op, T, 2>), dim3(grid), dim3(kThreads), 0, s, a);
+    else
+      hipLaunchKernelGGL((map_fields<Op, T, 1>), dim3(grid), dim3(kThreads), 0, s, a);
+  } else {
+    const unsigned long long step = (unsigned long long)grid * kThreads * V;
+    for (int i = 0; i < NIN; ++i) {
+      if (a.mode[i] == EKM_LEVEL_MAJOR) {
+        a.step_q[i] = step / a.inner[i];
+        a.step_r[i] = step % a.inner[i];
+      } else if (a.mode[i] == EKM_LEVEL_MINOR) {
+        a.step_r[i] = step % a.len[i];
+      }
+    }
+    hipLaunchKernelGGL((map_bcast<Op, T>), dim3(grid), dim3(kThreads), lds_elems * sizeof(T), s, a);
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return set_error(EKM_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));
+  return EKM_OK;
+}
+
+}  // namespace ekm

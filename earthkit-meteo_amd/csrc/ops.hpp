@@ -1,0 +1,145 @@
+// Point operators: one functor per C-ABI entry point.  Each maps NIN input
+// values of one grid point to NOUT output values; the map kernel
+// (map_kernel.hpp) and the host twin (host_twin.cpp) instantiate them.
+// `rp` is the op's real-valued parameter (eps of the reference signatures).
+#pragma once
+
+#include "thermo_math.hpp"
+
+namespace ekm {
+
+#define EKM_OP(NAME, NIN_, NOUT_, ...)                                      \
+  struct NAME {                                                              \
+    static constexpr int NIN = NIN_;                                         \
+    static constexpr int NOUT = NOUT_;                                       \
+    template <class T>                                                       \
+    EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T rp) { \
+      (void)rp;                                                              \
+      __VA_ARGS__                                                            \
+    }                                                                        \
+  };
+
+#define EKM_OP_T1(NAME, PARAM, NIN_, NOUT_, ...)                            \
+  template <int PARAM>                                                       \
+  struct NAME {                                                              \
+    static constexpr int NIN = NIN_;                                         \
+    static constexpr int NOUT = NOUT_;                                       \
+    template <class T>                                                       \
+    EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T rp) { \
+      (void)rp;                                                              \
+      __VA_ARGS__                                                            \
+    }                                                                        \
+  };
+
+#define EKM_OP_T2(NAME, P1, P2, NIN_, NOUT_, ...)                           \
+  template <int P1, int P2>                                                  \
+  struct NAME {                                                              \
+    static constexpr int NIN = NIN_;                                         \
+    static constexpr int NOUT = NOUT_;                                       \
+    template <class T>                                                       \
+    EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T rp) { \
+      (void)rp;                                                              \
+      __VA_ARGS__                                                            \
+    }                                                                        \
+  };
+
+// thermo.py:21-52
+EKM_OP(OpCelsiusToKelvin, 1, 1, y[0] = x[0] + T(k::T0);)
+EKM_OP(OpKelvinToCelsius, 1, 1, y[0] = x[0] - T(k::T0);)
+// thermo.py:55-102
+EKM_OP(OpQFromW, 1, 1, y[0] = q_from_w(x[0]);)
+EKM_OP(OpWFromQ, 1, 1, y[0] = w_from_q(x[0]);)
+// thermo.py:105-159
+EKM_OP(OpEFromQ, 2, 1, y[0] = e_from_q(x[0], x[1]);)
+EKM_OP(OpEFromW, 2, 1, y[0] = e_from_w(x[0], x[1]);)
+// thermo.py:162-232
+EKM_OP(OpQFromE, 2, 1, y[0] = q_from_e(x[0], x[1], rp);)
+EKM_OP(OpWFromE, 2, 1, y[0] = w_from_e(x[0], x[1], rp);)
+// thermo.py:235-341 (the inner q/w conversion runs with the default eps)
+EKM_OP_T1(OpSvp, PHASE, 1, 1, y[0] = es_phase<PHASE>(x[0]);)
+EKM_OP_T1(OpSatW, PHASE, 2, 1, y[0] = w_from_e(es_phase<PHASE>(x[0]), x[1], T(k::eps_default));)
+EKM_OP_T1(OpSatQ, PHASE, 2, 1, y[0] = q_from_e(es_phase<PHASE>(x[0]), x[1], T(k::eps_default));)
+// thermo.py:344-467
+EKM_OP_T1(OpSvpSlope, PHASE, 1, 1, T es; T des; es_slope_phase<PHASE>(x[0], es, des); y[0] = des;)
+EKM_OP_T1(OpSatWSlope, PHASE, 2, 1, T es; T des; es_slope_phase<PHASE>(x[0], es, des);
+          y[0] = ws_slope(x[1], es, des, rp);)
+EKM_OP_T1(OpSatQSlope, PHASE, 2, 1, T es; T des; es_slope_phase<PHASE>(x[0], es, des);
+          y[0] = qs_slope(x[1], es, des, rp);)
+// same with caller-supplied es / es_slope: inputs (p, es, es_slope)
+EKM_OP(OpSatWSlopeFromEs, 3, 1, y[0] = ws_slope(x[0], x[1], x[2], rp);)
+EKM_OP(OpSatQSlopeFromEs, 3, 1, y[0] = qs_slope(x[0], x[1], x[2], rp);)
+// thermo.py:470-491
+EKM_OP(OpTFromEs, 1, 1, y[0] = t_from_es(x[0]);)
+// thermo.py:494-556
+EKM_OP(OpRhFromTd, 2, 1, y[0] = m_div(T(100.0) * es_water(x[1]), es_water(x[0]));)
+EKM_OP(OpRhFromQ, 3, 1, y[0] = m_div(T(100.0) * e_from_q(x[1], x[2]), es_mixed(x[0]));)
+// thermo.py:559-663
+EKM_OP(OpQFromTd, 2, 1, y[0] = q_from_e(es_water(x[0]), x[1], T(k::eps_default));)
+EKM_OP(OpWFromTd, 2, 1, y[0] = w_from_e(es_water(x[0]), x[1], T(k::eps_default));)
+EKM_OP(OpQFromRh, 3, 1, y[0] = q_from_e(x[1] * es_mixed(x[0]) * T(1.0 / 100.0), x[2], T(k::eps_default));)
+// thermo.py:666-735
+EKM_OP(OpTdFromRh, 2, 1, y[0] = t_from_es(es_water(x[0]) * x[1] * T(1.0 / 100.0));)
+EKM_OP(OpTdFromQ, 2, 1, y[0] = t_from_es(e_from_q(x[0], x[1]));)
+// thermo.py:738-920
+EKM_OP(OpVirtualT, 2, 1, y[0] = virtual_t(x[0], x[1]);)
+EKM_OP(OpVirtualTheta, 3, 1, y[0] = theta(x[0], x[2]) * (T(1) + T(k::tv_c1) * x[1]);)
+EKM_OP(OpTheta, 2, 1, y[0] = theta(x[0], x[1]);)
+EKM_OP(OpTFromTheta, 2, 1, y[0] = t_from_theta(x[0], x[1]);)
+EKM_OP(OpPOnDryAdiabat, 3, 1, y[0] = p_on_dry_adiabat(x[0], x[1], x[2]);)
+EKM_OP(OpTOnDryAdiabat, 3, 1, y[0] = t_on_dry_adiabat(x[0], x[1], x[2]);)
+// thermo.py:923-1000
+EKM_OP_T1(OpLclT, METHOD, 2, 1, y[0] = lcl_t<METHOD>(x[0], x[1]);)
+EKM_OP_T1(OpLcl, METHOD, 3, 2, const T tl = lcl_t<METHOD>(x[0], x[1]); y[0] = tl;
+          y[1] = p_on_dry_adiabat(tl, x[0], x[2]);)
+// thermo.py:1326-1469
+EKM_OP_T1(OpEptFromTd, METHOD, 3, 1, y[0] = (ept<METHOD, false>(x[0], x[1], x[2]));)
+EKM_OP_T1(OpEptFromQ, METHOD, 3, 1, y[0] = (ept<METHOD, true>(x[0], x[1], x[2]));)
+EKM_OP_T1(OpSatEpt, METHOD, 2, 1, y[0] = ept_sat<METHOD>(x[0], x[1]);)
+// thermo.py:1472-1590
+EKM_OP_T2(OpTOnMa, METHOD, TM, 2, 1, y[0] = (t_on_ma<METHOD, TM>(x[0], x[1]));)
+EKM_OP_T2(OpWetBulbFromTd, METHOD, TM, 3, 1,
+          y[0] = (t_on_ma<METHOD, TM>(ept<METHOD, false>(x[0], x[1], x[2]), x[2]));)
+EKM_OP_T2(OpWetBulbFromQ, METHOD, TM, 3, 1,
+          y[0] = (t_on_ma<METHOD, TM>(ept<METHOD, true>(x[0], x[1], x[2]), x[2]));)
+// thermo.py:1593-1675: "direct" closed form, else the moist adiabat followed to p0
+template <int METHOD, int TM, class T>
+EKM_HD T wbpt_from_ept(T e) {
+  if (TM == T_DIRECT) return wbpt_direct(e);
+  return t_on_ma<METHOD, TM == T_DIRECT ? T_NEWTON : TM>(e, T(k::p0));
+}
+EKM_OP_T2(OpWbptFromTd, METHOD, TM, 3, 1, y[0] = wbpt_from_ept<METHOD, TM>(ept<METHOD, false>(x[0], x[1], x[2]));)
+EKM_OP_T2(OpWbptFromQ, METHOD, TM, 3, 1, y[0] = wbpt_from_ept<METHOD, TM>(ept<METHOD, true>(x[0], x[1], x[2]));)
+// thermo.py:1678-1707
+EKM_OP(OpGasConstant, 1, 1, y[0] = T(k::Rd) + T(k::Rv - k::Rd) * x[0];)
+
+// Fused compositions: one read of (t, q, p),
+// one write per output field.
+// P3: es = saturation_vapour_pressure(t); td = dewpoint_from_specific_humidity(q, p);
+//     rh = relative_humidity_from_specific_humidity(t, q, p)
+EKM_OP(OpPipelineSvpTdRh, 3, 3, const T es = es_mixed(x[0]); const T e = e_from_q(x[1], x[2]); y[0] = es;
+       y[1] = t_from_es(e); y[2] = m_div(T(100.0) * e, es);)
+
+// P5: theta, es, rh, td, theta_e(ifs), tw(ifs, newton); sub-expressions shared:
+// e(q,p) feeds td and rh, td feeds the LCL, theta feeds theta_e, theta_e feeds tw.
+struct OpPipelineFull {
+  static constexpr int NIN = 3;
+  static constexpr int NOUT = 6;
+  template <class T>
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T) {
+    const T t = x[0], q = x[1], p = x[2];
+    const T th = theta(t, p);
+    const T es = es_mixed(t);
+    const T e = e_from_q(q, p);
+    const T td = t_from_es(e);
+    const T tl = lcl_t<LCL_DAVIES>(t, td);
+    const T the = th * m_exp(m_div(T(k::K0_ifs) * q, tl));
+    y[0] = th;
+    y[1] = es;
+    y[2] = m_div(T(100.0) * e, es);
+    y[3] = td;
+    y[4] = the;
+    y[5] = t_on_ma_newton<EPT_IFS>(the, p);
+  }
+};
+
+}  // namespace ekm

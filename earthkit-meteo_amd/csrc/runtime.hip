@@ -1,0 +1,367 @@
+// Runtime half of libekm_thermo.so: device bookkeeping, memory / stream / event
+// wrappers, error reporting, launch tuning and the on-device synthetic input
+// generator.  Everything here is thin HIP plumbing behind the C ABI declared
+// in include/ekm_thermo.h; nothing throws across the boundary.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/ekm_thermo.h"
+#include "thermo_math.hpp"
+
+namespace ekm {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+static int hip_fail(hipError_t e, const char* what) {
+  return set_error(EKM_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define EKM_HIP(call)                                 \
+  do {                                                \
+    hipError_t e_ = (call);                           \
+    if (e_ != hipSuccess) return hip_fail(e_, #call); \
+  } while (0)
+
+constexpr int kMaxDev = 64;
+static int g_ndev = -1;
+static int g_cus[kMaxDev];
+static std::mutex g_mu;
+static std::atomic<int> g_blocks_per_cu{8};
+static std::atomic<int> g_unroll{1};
+
+static int probe() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_ndev >= 0) return EKM_OK;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return set_error(EKM_ERR_NODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  if (n > kMaxDev) n = kMaxDev;
+  for (int d = 0; d < n; ++d) {
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, d);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDeviceProperties");
+    g_cus[d] = prop.multiProcessorCount;
+  }
+  g_ndev = n;
+  return EKM_OK;
+}
+
+int use_device(int dev) {
+  int rc = probe();
+  if (rc != EKM_OK) return rc;
+  if (dev < 0 || dev >= g_ndev) return set_error(EKM_ERR_NODEV, "device %d of %d does not exist", dev, g_ndev);
+  EKM_HIP(hipSetDevice(dev));
+  return EKM_OK;
+}
+
+int device_cus(int dev) {
+  int rc = probe();
+  if (rc != EKM_OK) return rc;
+  if (dev < 0 || dev >= g_ndev) return set_error(EKM_ERR_NODEV, "device %d of %d does not exist", dev, g_ndev);
+  return g_cus[dev];
+}
+
+int tuning_blocks_per_cu() { return g_blocks_per_cu.load(std::memory_order_relaxed); }
+int tuning_unroll() { return g_unroll.load(std::memory_order_relaxed); }
+
+// ---- synthetic atmosphere on the device (SURVEY.md 8d distribution) ---------
+// Counter-based: every value is a pure function of (seed, global point index),
+// so shards of one global field can be filled independently on different GPUs.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ double u01(uint64_t bits) {  // (0, 1)
+  return ((bits >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+__host__ __device__ inline double synth_level_p(unsigned k, unsigned nlev) {
+  return nlev > 1 ? 1000.0 + (101325.0 - 1000.0) * (double)k / (double)(nlev - 1) : 101325.0;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void synth_fill(T* t, T* q, T* p, uint64_t first, size_t n, uint64_t inner,
+                                                 uint32_t nlev, uint64_t seed) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint64_t g = first + i;
+    uint64_t lev = g / inner;
+    if (lev >= nlev) lev = nlev - 1;
+    const uint64_t h0 = mix64(seed ^ (g * 0xd1342543de82ef95ull));
+    const uint64_t h1 = mix64(h0 + 1), h2 = mix64(h0 + 2), h3 = mix64(h0 + 3);
+    const double pl = synth_level_p((unsigned)lev, nlev);
+    // with a level-vector p (p == NULL) the point sits exactly on its level
+    const double pv = p ? pl * (1.0 + 0.05 * (2.0 * u01(h0) - 1.0)) : pl;
+    // Box-Muller normal, sigma = 8 K around the standard atmosphere
+    const double nrm = sqrt(-2.0 * log(u01(h1))) * cos(6.283185307179586 * u01(h2));
+    double tv = fmax(288.15 * pow(pv / 101325.0, 0.190263), 216.65) + 8.0 * nrm;
+    tv = fmin(fmax(tv, 180.0), 330.0);
+    const double rh = 1.0 + 99.0 * u01(h3);
+    // q = specific_humidity_from_relative_humidity(t, rh, p), capped (thermo.py:629-663)
+    const double e = rh * es_mixed<double>(tv) / 100.0;
+    double qv = q_from_e<double>(e, pv, 1e-4);
+    qv = fmin(qv, 0.04);
+    if (!(qv == qv)) qv = 3e-6;
+    t[i] = (T)tv;
+    q[i] = (T)qv;
+    if (p) p[i] = (T)pv;
+  }
+}
+
+template <class T>
+__global__ void synth_levels(T* pl, uint32_t nlev) {
+  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nlev) pl[k] = (T)synth_level_p(k, nlev);
+}
+
+template <class T>
+static int synth_fill_launch(int dev, void* stream, T* t, T* q, T* p, uint64_t first, size_t n, uint64_t inner,
+                             uint32_t nlev, uint64_t seed) {
+  if (n == 0) return EKM_OK;
+  if (!t || !q) return set_error(EKM_ERR_ARG, "synth_fill: null t/q pointer");
+  if (inner == 0 || nlev == 0) return set_error(EKM_ERR_ARG, "synth_fill: inner and nlev must be > 0");
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  const int cus = device_cus(dev);
+  if (cus <= 0) return cus;
+  size_t want = (n + 255) / 256, cap = (size_t)cus * 8;
+  const unsigned grid = (unsigned)(want < cap ? want : cap);
+  hipLaunchKernelGGL((synth_fill<T>), dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), t, q, p, first, n,
+                     inner, nlev, seed);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "synth_fill launch");
+  return EKM_OK;
+}
+
+template <class T>
+static int synth_levels_launch(int dev, void* stream, T* pl, uint32_t nlev) {
+  if (!pl || nlev == 0) return set_error(EKM_ERR_ARG, "synth_levels: bad arguments");
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  hipLaunchKernelGGL((synth_levels<T>), dim3((nlev + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), pl,
+                     nlev);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "synth_levels launch");
+  return EKM_OK;
+}
+
+}  // namespace ekm
+
+using namespace ekm;
+
+extern "C" {
+
+int ekm_init(void) { return probe(); }
+
+int ekm_device_count(void) {
+  int rc = probe();
+  return rc != EKM_OK ? rc : g_ndev;
+}
+
+const char* ekm_last_error(void) { return g_err; }
+
+const char* ekm_version(void) { return "ekm_thermo 0.1.0 (gfx950)"; }
+
+int ekm_device_name(int dev, char* buf, size_t buflen) {
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  if (!buf || buflen == 0) return set_error(EKM_ERR_ARG, "device_name: no buffer");
+  hipDeviceProp_t prop;
+  EKM_HIP(hipGetDeviceProperties(&prop, dev));
+  snprintf(buf, buflen, "%s (%s)", prop.name, prop.gcnArchName);
+  return EKM_OK;
+}
+
+int ekm_device_cus(int dev) { return device_cus(dev); }
+
+int ekm_mem_info(int dev, size_t* free_bytes, size_t* total_bytes) {
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  size_t f = 0, t = 0;
+  EKM_HIP(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return EKM_OK;
+}
+
+int ekm_malloc(int dev, size_t bytes, void** out) {
+  if (!out) return set_error(EKM_ERR_ARG, "malloc: null out pointer");
+  *out = nullptr;
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  EKM_HIP(hipMalloc(out, bytes ? bytes : 16));
+  return EKM_OK;
+}
+
+int ekm_free(int dev, void* ptr) {
+  if (!ptr) return EKM_OK;
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  EKM_HIP(hipFree(ptr));
+  return EKM_OK;
+}
+
+int ekm_host_alloc(size_t bytes, void** out) {
+  if (!out) return set_error(EKM_ERR_ARG, "host_alloc: null out pointer");
+  *out = nullptr;
+  int rc = probe();
+  if (rc != EKM_OK) return rc;
+  EKM_HIP(hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
+  return EKM_OK;
+}
+
+int ekm_host_free(void* ptr) {
+  if (!ptr) return EKM_OK;
+  EKM_HIP(hipHostFree(ptr));
+  return EKM_OK;
+}
+
+static int copy(int dev, void* dst, const void* src, size_t bytes, void* stream, hipMemcpyKind kind) {
+  if (bytes == 0) return EKM_OK;
+  if (!dst || !src) return set_error(EKM_ERR_ARG, "memcpy: null pointer");
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  EKM_HIP(hipMemcpyAsync(dst, src, bytes, kind, static_cast<hipStream_t>(stream)));
+  return EKM_OK;
+}
+
+int ekm_h2d(int dev, void* dst, const void* src, size_t bytes, void* stream) {
+  return copy(dev, dst, src, bytes, stream, hipMemcpyHostToDevice);
+}
+int ekm_d2h(int dev, void* dst, const void* src, size_t bytes, void* stream) {
+  return copy(dev, dst, src, bytes, stream, hipMemcpyDeviceToHost);
+}
+int ekm_d2d(int dev, void* dst, const void* src, size_t bytes, void* stream) {
+  return copy(dev, dst, src, bytes, stream, hipMemcpyDeviceToDevice);
+}
+
+int ekm_memset(int dev, void* dst, int value, size_t bytes, void* stream) {
+  if (bytes == 0) return EKM_OK;
+  if (!dst) return set_error(EKM_ERR_ARG, "memset: null pointer");
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  EKM_HIP(hipMemsetAsync(dst, value, bytes, static_cast<hipStream_t>(stream)));
+  return EKM_OK;
+}
+
+int ekm_sync(int dev) {
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  EKM_HIP(hipDeviceSynchronize());
+  return EKM_OK;
+}
+
+int ekm_stream_create(int dev, void** out) {
+  if (!out) return set_error(EKM_ERR_ARG, "stream_create: null out pointer");
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  hipStream_t s;
+  EKM_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *out = s;
+  return EKM_OK;
+}
+
+int ekm_stream_destroy(int dev, void* stream) {
+  if (!stream) return EKM_OK;
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  EKM_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+  return EKM_OK;
+}
+
+int ekm_stream_sync(int dev, void* stream) {
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  EKM_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return EKM_OK;
+}
+
+int ekm_event_create(int dev, void** out) {
+  if (!out) return set_error(EKM_ERR_ARG, "event_create: null out pointer");
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  hipEvent_t ev;
+  EKM_HIP(hipEventCreate(&ev));
+  *out = ev;
+  return EKM_OK;
+}
+
+int ekm_event_destroy(int dev, void* event) {
+  if (!event) return EKM_OK;
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  EKM_HIP(hipEventDestroy(static_cast<hipEvent_t>(event)));
+  return EKM_OK;
+}
+
+int ekm_event_record(int dev, void* event, void* stream) {
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  EKM_HIP(hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)));
+  return EKM_OK;
+}
+
+int ekm_event_sync(int dev, void* event) {
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  EKM_HIP(hipEventSynchronize(static_cast<hipEvent_t>(event)));
+  return EKM_OK;
+}
+
+int ekm_event_elapsed_ms(int dev, void* start, void* stop, float* ms) {
+  if (!ms) return set_error(EKM_ERR_ARG, "event_elapsed_ms: null out pointer");
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  EKM_HIP(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+  return EKM_OK;
+}
+
+int ekm_set_tuning(int blocks_per_cu, int unroll) {
+  if (blocks_per_cu < 0 || blocks_per_cu > 64 || unroll < 0 || unroll > 2)
+    return set_error(EKM_ERR_ARG, "set_tuning: blocks_per_cu in [1,64], unroll in {1,2} (0 keeps)");
+  if (blocks_per_cu) g_blocks_per_cu.store(blocks_per_cu);
+  if (unroll) g_unroll.store(unroll);
+  return EKM_OK;
+}
+
+int ekm_get_tuning(int* blocks_per_cu, int* unroll) {
+  if (blocks_per_cu) *blocks_per_cu = g_blocks_per_cu.load();
+  if (unroll) *unroll = g_unroll.load();
+  return EKM_OK;
+}
+
+int ekm_synth_fill_f32(int dev, void* stream, float* t, float* q, float* p, uint64_t first, size_t n, uint64_t inner,
+                       uint32_t nlev, uint64_t seed) {
+  return synth_fill_launch<float>(dev, stream, t, q, p, first, n, inner, nlev, seed);
+}
+int ekm_synth_fill_f64(int dev, void* stream, double* t, double* q, double* p, uint64_t first, size_t n,
+                       uint64_t inner, uint32_t nlev, uint64_t seed) {
+  return synth_fill_launch<double>(dev, stream, t, q, p, first, n, inner, nlev, seed);
+}
+int ekm_synth_levels_f32(int dev, void* stream, float* p_levels, uint32_t nlev) {
+  return synth_levels_launch<float>(dev, stream, p_levels, nlev);
+}
+int ekm_synth_levels_f64(int dev, void* stream, double* p_levels, uint32_t nlev) {
+  return synth_levels_launch<double>(dev, stream, p_levels, nlev);
+}
+
+}  // extern "C"

@@ -1,0 +1,422 @@
+// Per-grid-point thermodynamics, templated on the real type (float / double).
+//
+// One statement of the arithmetic for both the gfx950 kernels (kernels_*.hip)
+// and the host test twin (host_twin.cpp, test infrastructure only).  Every
+// function cites the reference lines it restates:
+//   thermo.py:N  = /root/reference/src/earthkit/meteo/thermo/array/thermo.py:N
+//   es_comp.py:N = /root/reference/src/earthkit/meteo/thermo/array/es_comp.py:N
+//
+// fp32 on the device goes through the CDNA4 transcendental unit directly
+// (v_exp_f32 / v_log_f32 / v_rcp_f32 via __builtin_amdgcn_*): no libm calls,
+// no IEEE division expansion.  NaN / inf semantics of the reference are kept
+// (no -ffast-math): rcp(0)=inf, log2(0)=-inf, log2(<0)=NaN, 0*inf=NaN.
+// fp64 has no hardware transcendentals; it uses the device libm (ocml).
+#pragma once
+
+#include <cmath>
+#include <limits>
+
+#if defined(__HIPCC__)
+#define EKM_HD __host__ __device__ __forceinline__
+#else
+#define EKM_HD inline
+#endif
+
+namespace ekm {
+
+// ---- constants (constants/constants.py:22-50, es_comp.py:14-20) -----------
+// Formed in double exactly as the Python literals/expressions are, then
+// rounded to the array dtype where they meet the data (NEP-50 weak scalars).
+namespace k {
+constexpr double Rd = 287.0597;
+constexpr double Rv = 461.51;
+constexpr double c_pd = 1004.79;
+constexpr double Lv = 2.5008e6;
+constexpr double kappa = 0.285691;
+constexpr double p0 = 1e5;
+constexpr double eps = 0.621981;
+constexpr double T0 = 273.16;
+constexpr double C1 = 611.21;
+constexpr double C3W = 17.502;
+constexpr double C4W = 32.19;
+constexpr double C3I = 22.587;
+constexpr double C4I = -0.7;
+constexpr double TI = T0 - 23;
+constexpr double lambda = 1.0 / kappa;            // thermo.py:1022
+constexpr double K0_ifs = Lv / c_pd;              // thermo.py:1164
+constexpr double q_c = eps * (1.0 / eps - 1.0);   // thermo.py:130
+constexpr double tv_c1 = (1.0 - eps) / eps;       // thermo.py:763
+constexpr double sw = C3W * (T0 - C4W);           // es_comp.py:170
+constexpr double si = C3I * (T0 - C4I);           // es_comp.py:174
+constexpr double dalpha_c = 2.0 / ((T0 - TI) * (T0 - TI));  // es_comp.py:193
+constexpr double eps_default = 1e-4;
+}  // namespace k
+
+enum Phase { PHASE_MIXED = 0, PHASE_WATER = 1, PHASE_ICE = 2 };
+enum EptMethod { EPT_IFS = 0, EPT_BOLTON35 = 1, EPT_BOLTON39 = 2 };
+enum TMethod { T_BISECT = 0, T_NEWTON = 1, T_DIRECT = 2 };
+enum LclMethod { LCL_DAVIES = 0, LCL_BOLTON = 1 };
+
+// ---- math primitives -------------------------------------------------------
+template <class T>
+EKM_HD T nan_v() {
+  return std::numeric_limits<T>::quiet_NaN();
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+EKM_HD float m_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+EKM_HD float m_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+EKM_HD float m_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+EKM_HD float m_log2(float x) { return __builtin_amdgcn_logf(x); }  // v_log_f32 is log2
+EKM_HD float m_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+EKM_HD float m_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
+EKM_HD float m_pow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+#else
+EKM_HD float m_rcp(float x) { return 1.0f / x; }
+EKM_HD float m_div(float a, float b) { return a / b; }
+EKM_HD float m_exp2(float x) { return std::exp2(x); }
+EKM_HD float m_log2(float x) { return std::log2(x); }
+EKM_HD float m_exp(float x) { return std::exp(x); }
+EKM_HD float m_log(float x) { return std::log(x); }
+EKM_HD float m_pow(float x, float y) { return std::pow(x, y); }
+#endif
+EKM_HD double m_rcp(double x) { return 1.0 / x; }
+EKM_HD double m_div(double a, double b) { return a / b; }
+EKM_HD double m_exp2(double x) { return exp2(x); }
+EKM_HD double m_log2(double x) { return log2(x); }
+EKM_HD double m_exp(double x) { return exp(x); }
+EKM_HD double m_log(double x) { return log(x); }
+EKM_HD double m_pow(double x, double y) { return pow(x, y); }
+
+template <class T>
+EKM_HD T m_sq(T x) {
+  return x * x;
+}
+
+// numpy.sign: -1 / 0 / +1, NaN stays NaN
+template <class T>
+EKM_HD T m_sign(T x) {
+  return x > T(0) ? T(1) : (x < T(0) ? T(-1) : (x == T(0) ? T(0) : x));
+}
+
+// ---- saturation vapour pressure (es_comp.py) -------------------------------
+template <class T>
+EKM_HD T es_water(T t) {  // es_comp.py:133-134
+  return T(k::C1) * m_exp(m_div(T(k::C3W) * (t - T(k::T0)), t - T(k::C4W)));
+}
+
+template <class T>
+EKM_HD T es_ice(T t) {  // es_comp.py:137-138
+  return T(k::C1) * m_exp(m_div(T(k::C3I) * (t - T(k::T0)), t - T(k::C4I)));
+}
+
+// es and d(es)/dT for one phase from one reciprocal (es_comp.py:169-174)
+template <class T>
+EKM_HD void es_slope_water(T t, T& es, T& des) {
+  const T r = m_rcp(t - T(k::C4W));
+  es = T(k::C1) * m_exp(T(k::C3W) * (t - T(k::T0)) * r);
+  des = es * T(k::sw) * (r * r);
+}
+
+template <class T>
+EKM_HD void es_slope_ice(T t, T& es, T& des) {
+  const T r = m_rcp(t - T(k::C4I));
+  es = T(k::C1) * m_exp(T(k::C3I) * (t - T(k::T0)) * r);
+  des = es * T(k::si) * (r * r);
+}
+
+// Mixed phase, branch-free (es_comp.py:141-166).  The reference gathers three
+// masks; per point that is: ice at t <= TI, water at t >= T0, alpha-blend in
+// between.  NaN fails both tests and lands in the blend, giving NaN.
+template <class T>
+EKM_HD T es_mixed(T t) {
+  const T ew = es_water(t);
+  const T ei = es_ice(t);
+  const T a = m_sq((t - T(k::TI)) * T(1.0 / (k::T0 - k::TI)));
+  const T mid = a * ew + (T(1) - a) * ei;
+  return t <= T(k::TI) ? ei : (t >= T(k::T0) ? ew : mid);
+}
+
+// es and slope of the mixed phase together (es_comp.py:177-200)
+template <class T>
+EKM_HD void es_slope_mixed(T t, T& es, T& des) {
+  T ew, dw, ei, di;
+  es_slope_water(t, ew, dw);
+  es_slope_ice(t, ei, di);
+  const T x = t - T(k::TI);
+  const T a = m_sq(x * T(1.0 / (k::T0 - k::TI)));
+  const T da = T(k::dalpha_c) * x;
+  const T mid = a * ew + (T(1) - a) * ei;
+  const T dmid = da * ew + a * dw - da * ei + (T(1) - a) * di;
+  const bool ice = t <= T(k::TI), wat = t >= T(k::T0);
+  es = ice ? ei : (wat ? ew : mid);
+  des = ice ? di : (wat ? dw : dmid);
+}
+
+template <int PHASE, class T>
+EKM_HD T es_phase(T t) {  // es_comp.py:31-79
+  if (PHASE == PHASE_WATER) return es_water(t);
+  if (PHASE == PHASE_ICE) return es_ice(t);
+  return es_mixed(t);
+}
+
+template <int PHASE, class T>
+EKM_HD void es_slope_phase(T t, T& es, T& des) {  // es_comp.py:82-106
+  if (PHASE == PHASE_WATER)
+    es_slope_water(t, es, des);
+  else if (PHASE == PHASE_ICE)
+    es_slope_ice(t, es, des);
+  else
+    es_slope_mixed(t, es, des);
+}
+
+template <class T>
+EKM_HD T t_from_es(T es) {  // es_comp.py:109-130 (always the water formula)
+  const T v = m_log(es * T(1.0 / k::C1));
+  return m_div(v * T(k::C4W) - T(k::C3W * k::T0), v - T(k::C3W));
+}
+
+// ---- humidity conversions ---------------------------------------------------
+template <class T>
+EKM_HD T e_from_q(T q, T p) {  // thermo.py:105-131
+  return m_div(p * q, T(k::eps) + T(k::q_c) * q);
+}
+
+template <class T>
+EKM_HD T e_from_w(T w, T p) {  // thermo.py:134-159
+  return m_div(p * w, T(k::eps) + w);
+}
+
+template <class T>
+EKM_HD T q_from_e(T e, T p, T epsv) {  // thermo.py:162-196
+  T v = p + T(k::eps - 1) * e;
+  if ((p - e) < epsv) v = nan_v<T>();
+  return m_div(T(k::eps) * e, v);
+}
+
+template <class T>
+EKM_HD T w_from_e(T e, T p, T epsv) {  // thermo.py:199-232
+  T v = p - e;
+  if (v < epsv) v = nan_v<T>();
+  return m_div(T(k::eps) * e, v);
+}
+
+template <class T>
+EKM_HD T w_from_q(T q) {  // thermo.py:80-102
+  return m_div(q, T(1) - q);
+}
+
+template <class T>
+EKM_HD T q_from_w(T w) {  // thermo.py:55-77
+  return m_div(w, T(1) + w);
+}
+
+// d(ws)/dT = eps*des*p/(p-es)^2, NaN where p-es < eps (thermo.py:367-415)
+template <class T>
+EKM_HD T ws_slope(T p, T es, T des, T epsv) {
+  T v = p - es;
+  if (v < epsv) v = nan_v<T>();
+  const T r = m_rcp(v);
+  return T(k::eps) * des * p * (r * r);
+}
+
+// d(qs)/dT = eps*des*p/(p+es*(eps-1))^2, NaN where p-es < eps (thermo.py:418-467)
+template <class T>
+EKM_HD T qs_slope(T p, T es, T des, T epsv) {
+  T v = m_sq(p + es * T(k::eps - 1.0));
+  if ((p - es) < epsv) v = nan_v<T>();
+  return m_div(T(k::eps) * des * p, v);
+}
+
+// ---- dry thermodynamics ------------------------------------------------------
+template <class T>
+EKM_HD T theta(T t, T p) {  // thermo.py:801-829
+  return t * m_pow(m_div(T(k::p0), p), T(k::kappa));
+}
+
+template <class T>
+EKM_HD T t_from_theta(T th, T p) {  // thermo.py:832-858
+  return th * m_pow(p * T(1.0 / k::p0), T(k::kappa));
+}
+
+template <class T>
+EKM_HD T p_on_dry_adiabat(T t, T t_def, T p_def) {  // thermo.py:861-889
+  return p_def * m_pow(m_div(t, t_def), T(1 / k::kappa));
+}
+
+template <class T>
+EKM_HD T t_on_dry_adiabat(T p, T t_def, T p_def) {  // thermo.py:892-920
+  return t_def * m_pow(m_div(p, p_def), T(k::kappa));
+}
+
+template <class T>
+EKM_HD T virtual_t(T t, T q) {  // thermo.py:738-764
+  return t * (T(1) + T(k::tv_c1) * q);
+}
+
+template <int METHOD, class T>
+EKM_HD T lcl_t(T t, T td) {  // thermo.py:923-968
+  if (METHOD == LCL_DAVIES)
+    return td - (T(0.212) + T(1.571e-3) * (td - T(k::T0)) - T(4.36e-4) * (t - T(k::T0))) * (t - td);
+  return T(56.0) + m_rcp(m_rcp(td - T(56)) + m_log(m_div(t, td)) * T(1.0 / 800));
+}
+
+// ---- equivalent potential temperature (thermo.py:1020-1323) ------------------
+// HAVE_Q: humidity given as specific humidity q (td derived from it,
+// thermo.py:1036-1037); otherwise as dewpoint td.
+template <int METHOD, bool HAVE_Q, class T>
+EKM_HD T ept(T t, T hum, T p) {
+  T td, q = T(0);
+  if (HAVE_Q) {
+    q = hum;
+    td = t_from_es(e_from_q(q, p));  // thermo.py:702-735
+  } else {
+    td = hum;
+  }
+  if (METHOD == EPT_IFS) {  // thermo.py:1169-1175
+    const T th = theta(t, p);
+    const T tl = lcl_t<LCL_DAVIES>(t, td);
+    if (!HAVE_Q) q = q_from_e(es_water(td), p, T(k::eps_default));
+    return th * m_exp(m_div(T(k::K0_ifs) * q, tl));
+  }
+  const T tl = lcl_t<LCL_BOLTON>(t, td);
+  const T w = HAVE_Q ? w_from_q(q) : w_from_e(es_water(td), p, T(k::eps_default));
+  if (METHOD == EPT_BOLTON35) {  // thermo.py:1205-1213
+    const T th = t * m_pow(m_div(T(k::p0), p), T(k::kappa) * (T(1) - T(0.28) * w));
+    return th * m_exp(m_div(T(2675.0) * w, tl));
+  }
+  // bolton39, thermo.py:1268-1278
+  const T e = e_from_w(w, p);
+  const T th = theta(t, p - e) * m_pow(m_div(t, tl), T(0.28) * w);
+  return th * m_exp((m_div(T(3036.0), tl) - T(1.78)) * w * (T(1) + T(0.448) * w));
+}
+
+// th_sat and G_sat(scale) of the saturated parcel (thermo.py:1177-1182,
+// 1215-1224, 1280-1295).  bolton39 masks es where p - es < 1e-4.
+template <int METHOD, class T>
+EKM_HD void sat_terms(T t, T p, T scale, T& th_sat, T& g_sat) {
+  T es = es_mixed(t);
+  if (METHOD == EPT_IFS) {
+    th_sat = theta(t, p);
+    const T qs = q_from_e(es, p, T(k::eps_default));
+    g_sat = m_div((scale * T(k::K0_ifs)) * qs, t);
+  } else if (METHOD == EPT_BOLTON35) {
+    const T ws = w_from_e(es, p, T(k::eps_default));
+    th_sat = t * m_pow(m_div(T(k::p0), p), T(k::kappa) * (T(1) - T(0.28) * ws));
+    g_sat = m_div((scale * T(2675.0)) * ws, t);
+  } else {
+    if ((p - es) < T(1e-4)) es = nan_v<T>();
+    th_sat = theta(t, p - es);
+    const T ws = w_from_e(es, p, T(k::eps_default));
+    g_sat = (m_div(scale * T(3036.0), t) - scale * T(1.78)) * ws * (T(1) + T(0.448) * ws);
+  }
+}
+
+template <int METHOD, class T>
+EKM_HD T ept_sat(T t, T p) {  // thermo.py:1042-1045
+  T th, g;
+  sat_terms<METHOD>(t, p, T(1), th, g);
+  return th * m_exp(g);
+}
+
+// Horner with ascending coefficients (the namespace's polyval(x, c))
+template <class T>
+EKM_HD T poly2(T x, double c0, double c1, double c2) {
+  return T(c0) + (T(c1) + T(c2) * x) * x;
+}
+
+template <class T>
+EKM_HD T wbpt_direct(T e) {  // thermo.py:1047-1053
+  const T x = e * T(1.0 / 273.16);
+  const T a = T(7.101574) + (T(-20.68208) + (T(16.11182) + (T(2.574631) + T(-5.205688) * x) * x) * x) * x;
+  const T b = T(1.0) + (T(-3.552497) + (T(3.781782) + (T(-0.6899655) + T(-0.5929340) * x) * x) * x) * x;
+  return e - m_exp(m_div(a, b));
+}
+
+// Moist-adiabat inversion by 12 fixed halvings (thermo.py:1055-1079)
+template <int METHOD, class T>
+EKM_HD T t_on_ma_bisect(T e, T p) {
+  T t = T(k::T0 - 20);
+  T dt = T(120.0);
+#pragma unroll 1
+  for (int it = 0; it < 12; ++it) {
+    T th, g;
+    sat_terms<METHOD>(t, p, T(-1.0), th, g);
+    dt *= T(0.5);
+    t += m_sign(e * m_exp(g) - th) * dt;
+  }
+  return t;
+}
+
+// Davies-Jones (2008): regime initial guess + exactly one Newton step
+// (max_iter = 1, thermo.py:1104), tw <= 0 -> NaN (thermo.py:1081-1159).
+template <int METHOD, class T>
+EKM_HD T t_on_ma_newton(T e, T p) {
+  const T t0 = T(273.16);
+  const T A = T(2675);
+  const T lam = T(k::lambda);
+  const T pr = p * T(1.0 / k::p0);
+  const T pp = m_pow(pr, T(k::kappa));
+  const T te = e * pp;
+  const T c_te = m_pow(m_div(t0, te), lam);
+  const T D = m_rcp(T(0.1859e-5) * p + T(0.6512));
+
+  // initial guess (deg C); later regimes overwrite earlier ones (thermo.py:1114-1128)
+  T tw = e;
+  {
+    T es, des;
+    es_slope_mixed(te, es, des);
+    const T ws = w_from_e(es, p, T(k::eps_default));
+    const T aw = A * ws;
+    const T g1 = te - t0 - m_div(aw, T(1) + m_div(aw * des, es));
+    const T k1 = poly2(pp, -53.737, 137.81, -38.5);
+    const T k2 = poly2(pp, -0.384, 56.831, -4.392);
+    if (c_te > D) tw = g1;
+    if (T(1) <= c_te && c_te <= D) tw = k1 - k2 * c_te;
+    if (T(0.4) <= c_te && c_te < T(1)) tw = (k1 - T(1.21)) - (k2 - T(1.21)) * c_te;
+    if (c_te < T(0.4)) tw = (k1 - T(2.66)) - (k2 - T(1.21)) * c_te + m_div(T(0.58), c_te);
+  }
+  tw = tw + T(k::T0);
+
+  // one Newton step (thermo.py:1132-1149)
+  {
+    const T rtw = m_rcp(tw);
+    const T c_tw = m_pow(t0 * rtw, lam);
+    T es, des;
+    es_slope_mixed(tw, es, des);
+    T f, dlnf;
+    if (METHOD == EPT_IFS) {  // thermo.py:1184-1197
+      const T qs = q_from_e(es, p, T(k::eps_default));
+      f = c_tw * m_exp((-lam * T(k::K0_ifs)) * qs * rtw);
+      const T dqs = qs_slope(p, es, des, T(k::eps_default));
+      const T dg = -T(k::K0_ifs) * qs * (rtw * rtw) + T(k::K0_ifs) * dqs * rtw;
+      dlnf = -lam * (rtw + dg);
+    } else if (METHOD == EPT_BOLTON35) {  // thermo.py:1226-1250
+      const T ws = w_from_e(es, p, T(k::eps_default));
+      f = c_tw * m_pow(pr, T(0.28) * ws) * m_exp((-lam * T(2675.0)) * ws * rtw);
+      const T dws = ws_slope(p, es, des, T(k::eps_default));
+      const T dg = -T(2675.0) * ws * (rtw * rtw) + T(2675.0) * dws * rtw;
+      // the middle term multiplies the *es* slope, as the reference does
+      dlnf = -lam * (rtw + T(0.28) * m_log(pr) * des + dg);
+    } else {  // bolton39, thermo.py:1297-1316 (es un-masked here)
+      const T ws = w_from_e(es, p, T(k::eps_default));
+      const T g = ((-lam * T(3036.0)) * rtw - (-lam * T(1.78))) * ws * (T(1) + T(0.448) * ws);
+      f = c_tw * (T(1) - m_div(es, p)) * m_exp(g);
+      const T dws = ws_slope(p, es, des, T(k::eps_default));
+      const T dg = -T(3036.0) * (ws + T(0.448) * (ws * ws)) * (rtw * rtw) +
+                   (T(3036.0) * rtw - T(1.78)) * (T(1) + T(2 * 0.448) * ws) * dws;
+      dlnf = -lam * (rtw + m_div(T(k::kappa) * des, p - es) + dg);
+    }
+    tw -= m_div(f - c_te, f * dlnf);
+  }
+  if (tw <= T(0)) tw = nan_v<T>();  // thermo.py:1155
+  return tw;
+}
+
+template <int METHOD, int TM, class T>
+EKM_HD T t_on_ma(T e, T p) {  // thermo.py:1472-1509
+  if (TM == T_BISECT) return t_on_ma_bisect<METHOD>(e, p);
+  return t_on_ma_newton<METHOD>(e, p);
+}
+
+}  // namespace ekm

@@ -1,0 +1,162 @@
+"""Argument normalisation and launch: the host logic between the reference's
+Python signatures (ekm_hip.thermo) and the C ABI (libekm_thermo.so).
+
+What it reproduces from the reference:
+ * inputs may be Python scalars, lists, 0-d / N-d arrays, mutually broadcastable;
+ * output dtype is NumPy's promotion of the inputs with Python scalars weak
+   (fp32 arrays stay fp32), integers and lists promote to float64;
+ * inputs are never mutated, outputs are fresh arrays;
+ * all-scalar calls return a NumPy scalar.
+What it adds: `DeviceArray` inputs keep the whole call on the GPU and return
+DeviceArrays; broadcast operands (a scalar, a level vector along the leading or
+trailing axes) are passed to the kernels as such instead of being materialised.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._optable import OPS
+from .device import DeviceArray, current_device, current_stream
+
+_F32, _F64 = np.dtype(np.float32), np.dtype(np.float64)
+_MAX_LDS_BYTES = 64 * 1024
+_MIN_VEC = 4  # a LEVEL operand must span at least one 16-B chunk per level
+
+
+def _result_dtype(args):
+    """NumPy promotion with weak Python scalars; anything non-float computes in float64."""
+    parts = []
+    for a in args:
+        if isinstance(a, DeviceArray):
+            parts.append(a.dtype)
+        elif isinstance(a, (bool, int, float)):
+            parts.append(a)
+        else:
+            parts.append(np.asarray(a).dtype if not isinstance(a, (np.ndarray, np.generic)) else a.dtype)
+    rd = np.result_type(*parts, 0.0) if parts else _F64
+    if rd == np.float16:
+        return np.dtype(np.float16), _F32
+    if rd == _F32:
+        return _F32, _F32
+    if rd.kind in "fiub":
+        return _F64, _F64
+    raise TypeError(f"unsupported dtype for thermo computation: {rd}")
+
+
+def _padded(shape, ndim):
+    return (1,) * (ndim - len(shape)) + tuple(shape)
+
+
+def classify(shape, out_shape):
+    """How an operand of `shape` broadcasts to `out_shape`.
+
+    Returns (mode, len, inner) with mode one of FIELD / SCALAR / LEVEL_MAJOR /
+    LEVEL_MINOR, or None when the pattern needs materialising.
+    """
+    size = int(np.prod(shape, dtype=np.int64))
+    n = int(np.prod(out_shape, dtype=np.int64))
+    if size == 1 and n != 1:
+        return _ffi.SCALAR, 0, 0
+    s = _padded(shape, len(out_shape))
+    if s == tuple(out_shape):
+        return _ffi.FIELD, 0, 0
+    nz = [i for i, d in enumerate(s) if d != 1]
+    lo, hi = nz[0], nz[-1]
+    if any(s[i] != out_shape[i] for i in range(lo, hi + 1)):
+        return None  # a 1 in the middle of the block: not a plain vector
+    if lo == 0 or all(out_shape[i] == 1 for i in range(lo)):
+        # varies along the leading axes only: value index = flat_index // inner
+        inner = int(np.prod(out_shape[hi + 1:], dtype=np.int64))
+        if inner >= _MIN_VEC:
+            return _ffi.LEVEL_MAJOR, size, inner
+    if hi == len(out_shape) - 1:
+        # varies along the trailing axes only: value index = flat_index % len
+        if size >= _MIN_VEC:
+            return _ffi.LEVEL_MINOR, size, 0
+    return None
+
+
+class _Plan:
+    """Normalised operands of one call."""
+
+    def __init__(self, args, dtype_override=None):
+        self.on_device = any(isinstance(a, DeviceArray) for a in args)
+        self.out_dtype, self.dtype = _result_dtype(args)
+        if dtype_override is not None:
+            self.out_dtype = self.dtype = np.dtype(dtype_override)
+        devs = {a.device for a in args if isinstance(a, DeviceArray)}
+        if len(devs) > 1:
+            raise ValueError(f"inputs live on different devices: {sorted(devs)}")
+        self.device = devs.pop() if devs else current_device()
+        self.all_scalar = all(np.ndim(a) == 0 for a in args if not isinstance(a, DeviceArray)) and not self.on_device
+        self.host = []
+        shapes = []
+        for a in args:
+            if isinstance(a, DeviceArray):
+                self.host.append(a)
+                shapes.append(a.shape)
+            else:
+                h = np.asarray(a)
+                self.host.append(h)
+                shapes.append(h.shape)
+        self.shape = tuple(np.broadcast_shapes(*shapes))
+        self.n = int(np.prod(self.shape, dtype=np.int64))
+
+
+def run(name, args, ints=(), eps=None, dtype=None):
+    """Launch entry point `name` on `args`; returns a tuple of outputs."""
+    ins, outs, int_names, has_eps = OPS[name]
+    assert len(args) == len(ins) and len(ints) == len(int_names)
+    plan = _Plan(args, dtype)
+    lib = _ffi.lib()
+    dev, stream = plan.device, current_stream()
+    tag = "f32" if plan.dtype == _F32 else "f64"
+    fn = getattr(lib, f"ekm_{name}_{tag}")
+
+    temps = []  # device buffers owned by this call
+    operands = []
+    lds_bytes = 0
+    for a in plan.host:
+        shape = a.shape
+        cls = classify(shape, plan.shape) if plan.n else (_ffi.FIELD, 0, 0)
+        if cls is not None and cls[0] >= _ffi.LEVEL_MAJOR:
+            nb = cls[1] * plan.dtype.itemsize
+            if lds_bytes + nb > _MAX_LDS_BYTES:
+                cls = None
+            else:
+                lds_bytes += (nb + 15) & ~15
+        if isinstance(a, DeviceArray) and cls is not None and a.dtype == plan.dtype:
+            darr = a
+        else:
+            h = np.asarray(a)  # DeviceArray -> host copy only on the slow path
+            if cls is None:
+                h = np.broadcast_to(h.reshape(_padded(h.shape, len(plan.shape))), plan.shape)
+                cls = (_ffi.FIELD, 0, 0)
+            darr = DeviceArray.from_host(np.ascontiguousarray(h, dtype=plan.dtype), device=dev)
+            temps.append(darr)
+        operands.append(_ffi.Operand(darr.ptr, cls[0], 0, cls[1], cls[2]))
+
+    results = [DeviceArray.empty(plan.shape, plan.dtype, dev) for _ in outs]
+    cargs = [dev, stream] + [C.byref(o) for o in operands] + [int(v) for v in ints]
+    if has_eps:
+        cargs.append(float(eps))
+    cargs += [r.ptr for r in results] + [plan.n]
+    _ffi.check(fn(*cargs))
+
+    if plan.on_device:
+        # temporaries are freed by HIP in stream order after the kernel has run
+        for t in temps:
+            t.free()
+        return tuple(results)
+
+    host = []
+    for r in results:
+        h = r.to_host()  # synchronises the stream
+        r.free()
+        if plan.out_dtype != plan.dtype:
+            h = h.astype(plan.out_dtype)
+        host.append(h[()] if plan.all_scalar else h)
+    for t in temps:
+        t.free()
+    return tuple(host)

