@@ -1,0 +1,355 @@
+#!/usr/bin/env python3
+"""Benchmark of the fused thermo pipeline on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload full|p3|wetbulb|...]
+
+A "step" is one pass of the hot path over one 0.1-degree global field
+(3600 x 1800 x 137 fp32 grid points per variable) resident in HBM: one launch of
+the fused kernel, inputs generated on the device beforehand (synthetic, seeded).
+N > 1 is one process per GPU (the driver launches it through
+torch.distributed.run); grid points are independent, so ranks share nothing and
+the only communication is the timing barrier / max-reduce, done over gloo on the
+CPU so that PyTorch never touches the GPUs the HIP library is using.
+
+Rank 0 prints ONE JSON line: the contract fields plus `roofline` (algorithmic
+bytes / HIP-event kernel time against the 8 TB/s HBM peak), `cpu_baseline` (the
+NumPy oracle timed on this box's host cores on a bounded sample, N = 1 only) and
+`parity` (GPU output vs the oracle on points sampled from the timed arrays).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "earthkit-meteo_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+NLEV, NLAT, NLON = 137, 1800, 3600
+INNER = NLAT * NLON
+N3 = NLEV * INNER
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+# workload -> (entry point, inputs, outputs, algorithmic bytes/point fp32 with p a full field, oracle call)
+WORKLOADS = {
+    "full": ("pipeline_full", 3, 6, 36, "fused theta+es+rh+td+theta_e+tw(ifs,newton)"),
+    "p3": ("pipeline_svp_td_rh", 3, 3, 24, "fused es+td+rh"),
+    "wetbulb": ("wet_bulb_temperature_from_specific_humidity", 3, 1, 16, "wet-bulb (ifs, newton)"),
+    "wetbulb_bisect": ("wet_bulb_temperature_from_specific_humidity", 3, 1, 16, "wet-bulb (ifs, bisect)"),
+    "rh": ("relative_humidity_from_specific_humidity", 3, 1, 16, "rh from q"),
+    "theta": ("potential_temperature", 2, 1, 12, "potential temperature"),
+    "svp": ("saturation_vapour_pressure", 1, 1, 8, "saturation vapour pressure (mixed)"),
+    "ept": ("ept_from_specific_humidity", 3, 1, 16, "theta_e (ifs)"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="full", choices=sorted(WORKLOADS))
+    ap.add_argument("--pmode", default="field", choices=["field", "level"],
+                    help="pressure as a full field, or as the 137-level vector staged in LDS")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: one full global field per GPU; strong: one global field split across GPUs")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--levels", type=int, default=NLEV, help="levels per field (137 = the named config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 20, help="points per worker for the CPU baseline")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="exercise rendezvous/sharding/reporting without touching a GPU (CI on CPU); value is null")
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--unroll", type=int, default=0)
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------
+def oracle_call(workload, t, q, p):
+    from oracle import thermo_oracle as orc
+
+    with np.errstate(all="ignore"):
+        if workload == "full":
+            return orc.pipeline_full(t, q, p)
+        if workload == "p3":
+            return orc.pipeline_svp_td_rh(t, q, p)
+        if workload == "wetbulb":
+            return (orc.wet_bulb_temperature_from_specific_humidity(t, q, p, "ifs", "newton"),)
+        if workload == "wetbulb_bisect":
+            return (orc.wet_bulb_temperature_from_specific_humidity(t, q, p, "ifs", "bisect"),)
+        if workload == "rh":
+            return (orc.relative_humidity_from_specific_humidity(t, q, p),)
+        if workload == "theta":
+            return (orc.potential_temperature(t, p),)
+        if workload == "svp":
+            return (orc.saturation_vapour_pressure(t),)
+        if workload == "ept":
+            return (orc.ept_from_specific_humidity(t, q, p),)
+    raise KeyError(workload)
+
+
+def _cpu_worker(job):
+    workload, npts, seed, dtype = job
+    from oracle import synthetic
+
+    t, q, p, _ = synthetic.make_fields(8, npts // 8, dtype=np.dtype(dtype), seed=seed)
+    t, q, p = t.ravel(), q.ravel(), p.ravel()
+    best = float("inf")
+    for _ in range(2):
+        t0 = time.perf_counter()
+        oracle_call(workload, t, q, p)
+        best = min(best, time.perf_counter() - t0)
+    return t.size, best
+
+
+def cpu_baseline(workload, sample, dtype):
+    """The NumPy oracle (same operator sequence as the reference) on the host cores: one
+    process per core, each on its own slab of the benchmark distribution.  Must run before
+    this process initialises HIP (fork)."""
+    import multiprocessing as mp
+
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    n1, t1 = _cpu_worker((workload, sample, 1, dtype))
+    jobs = [(workload, sample, 100 + i, dtype) for i in range(cores)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - t0
+    pts = sum(r[0] for r in res)
+    slowest = max(r[1] for r in res)
+    return {
+        "value": pts / slowest, "unit": "grid-points/s", "cores": cores, "kind": "port",
+        "value_1core": n1 / t1,
+        "sample": f"{cores} workers x {sample} points of the synthetic atmosphere (8 levels each), NumPy oracle "
+                  f"oracle/thermo_oracle.py ({workload}), best of 2 per worker, all workers concurrent; "
+                  f"pool wall {wall:.1f} s",
+    }
+
+
+# ---------------------------------------------------------------------------------------------
+class Dist:
+    """Timing barrier / max-reduce across ranks (gloo on the CPU; no data-path collective exists)."""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
+        self.td = None
+        if self.world > 1:
+            import datetime
+
+            import torch.distributed as td
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            td.init_process_group("gloo", rank=self.rank, world_size=self.world,
+                                  timeout=datetime.timedelta(seconds=600))
+            self.td = td
+
+    def barrier(self):
+        if self.td:
+            self.td.barrier()
+
+    def reduce(self, value, op="max"):
+        if not self.td:
+            return value
+        import torch
+
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self.td.all_reduce(t, op=getattr(self.td.ReduceOp, op.upper()))
+        return float(t[0])
+
+    def close(self):
+        if self.td:
+            self.td.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # convenience: relaunch under torch.distributed.run as a child (nothing has touched the GPU yet)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    dist = Dist()
+    entry, nin, nout, bpp, desc = WORKLOADS[args.workload]
+    itemsize = 4 if args.dtype == "f32" else 8
+    np_dtype = np.float32 if args.dtype == "f32" else np.float64
+    bpp = bpp * itemsize // 4
+    if args.pmode == "level" and nin >= 2:
+        bpp -= itemsize  # p is not read per point
+    nlev = args.levels
+    n_field = nlev * INNER
+    if args.scaling == "weak":
+        first, n_local = 0, n_field          # every rank owns one whole global field
+        n_total = n_field * dist.world
+    else:
+        from ekm_hip.device import shard_bounds
+
+        lo, hi = shard_bounds(n_field, dist.world)[dist.rank]
+        first, n_local = lo, hi - lo
+        n_total = n_field
+
+    cpu = None
+    if dist.rank == 0 and dist.world == 1 and not args.no_cpu_baseline and not args.dry_run:
+        cpu = cpu_baseline(args.workload, args.cpu_sample, np_dtype)  # before HIP is initialised (fork)
+
+    kernel_ms, parity = None, None
+    if args.dry_run:
+        step = lambda: None  # noqa: E731
+        sync = lambda: None  # noqa: E731
+    else:
+        import ekm_hip
+        from ekm_hip import _ffi
+        from ekm_hip.device import DeviceArray
+
+        lib = _ffi.lib()
+        ndev = ekm_hip.device_count()
+        dev = dist.local_rank % ndev
+        ekm_hip.set_device(dev)
+        if args.blocks_per_cu or args.unroll:
+            _ffi.check(lib.ekm_set_tuning(args.blocks_per_cu, args.unroll))
+        shape = (n_local,)
+        t = DeviceArray.empty(shape, np_dtype, dev)
+        q = DeviceArray.empty(shape, np_dtype, dev)
+        p = DeviceArray.empty(shape, np_dtype, dev) if args.pmode == "field" else None
+        fill = getattr(lib, f"ekm_synth_fill_{args.dtype}")
+        seed = 20260313 + (dist.rank if args.scaling == "weak" else 0)
+        _ffi.check(fill(dev, None, t.ptr, q.ptr, p.ptr if p else None, first, n_local, INNER, nlev, seed))
+        plev = DeviceArray.empty((nlev,), np_dtype, dev)
+        _ffi.check(getattr(lib, f"ekm_synth_levels_{args.dtype}")(dev, None, plev.ptr, nlev))
+        outs = [DeviceArray.empty(shape, np_dtype, dev) for _ in range(nout)]
+
+        fn = getattr(lib, f"ekm_{entry}_{args.dtype}")
+        F = _ffi.Operand
+        op_t, op_q = F(t.ptr, _ffi.FIELD, 0, 0, 0), F(q.ptr, _ffi.FIELD, 0, 0, 0)
+        if p is not None:
+            op_p = F(p.ptr, _ffi.FIELD, 0, 0, 0)
+        else:  # level vector: index = (first + i) // INNER; shards start on a level boundary only at rank 0,
+            # so a shard passes the sub-vector starting at its first level and an offset-free inner
+            assert first % INNER == 0 or args.scaling == "weak", "level mode needs level-aligned shards"
+            lev0 = first // INNER
+            op_p = F(plev.ptr + lev0 * itemsize, _ffi.LEVEL_MAJOR, 0, nlev - lev0, INNER)
+        operands = {"pipeline_full": (op_t, op_q, op_p), "pipeline_svp_td_rh": (op_t, op_q, op_p),
+                    "wet_bulb_temperature_from_specific_humidity": (op_t, op_q, op_p),
+                    "relative_humidity_from_specific_humidity": (op_t, op_q, op_p),
+                    "ept_from_specific_humidity": (op_t, op_q, op_p),
+                    "potential_temperature": (op_t, op_p), "saturation_vapour_pressure": (op_t,)}[entry]
+        ints = {"wetbulb": (0, 1), "wetbulb_bisect": (0, 0), "svp": (0,), "ept": (0,)}.get(args.workload, ())
+        cargs = [dev, None] + [C.byref(o) for o in operands] + list(ints) + [o.ptr for o in outs] + [n_local]
+
+        def step():
+            _ffi.check(fn(*cargs))
+
+        def sync():
+            _ffi.check(lib.ekm_sync(dev))
+
+        ev0, ev1 = C.c_void_p(), C.c_void_p()
+        _ffi.check(lib.ekm_event_create(dev, C.byref(ev0)))
+        _ffi.check(lib.ekm_event_create(dev, C.byref(ev1)))
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    if not args.dry_run:
+        _ffi.check(lib.ekm_event_record(dev, ev0, None))  # same (default) stream the kernels are launched on
+    for _ in range(args.steps):
+        step()
+    if not args.dry_run:
+        _ffi.check(lib.ekm_event_record(dev, ev1, None))
+    sync()
+    dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    elapsed = dist.reduce(elapsed, "max")
+
+    if not args.dry_run:
+        ms = C.c_float()
+        _ffi.check(lib.ekm_event_elapsed_ms(dev, ev0, ev1, C.byref(ms)))
+        kernel_ms = dist.reduce(ms.value / args.steps, "max")  # average launch duration, slowest rank
+        if dist.rank == 0:
+            parity = check_parity(args, t, q, p, plev, outs, n_local, first, nlev, np_dtype)
+
+    if dist.rank == 0:
+        value = None if args.dry_run else n_total * args.steps / elapsed
+        roof = None
+        if kernel_ms:
+            achieved = bpp * n_local / (kernel_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles(args),
+                    "kernel": entry, "bytes_per_point": bpp, "points_per_launch": n_local,
+                    "kernel_ms": round(kernel_ms, 4)}
+        line = {
+            "metric": "grid-points/sec for fused thermo pipeline; achieved HBM GB/s vs peak",
+            "value": value, "unit": "grid-points/s", "n_gpus": dist.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": None if args.dry_run else round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"{desc} on {nlev}x{NLAT}x{NLON} {args.dtype} "
+                                   f"({'one field per GPU' if args.scaling == 'weak' else 'one field split by grid point'}),"
+                                   f" p as {'full field' if args.pmode == 'field' else '137-level vector in LDS'}",
+                       "entry_point": f"ekm_{entry}_{args.dtype}", "points_per_gpu": n_local, "p_mode": args.pmode},
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+        }
+        if args.dry_run:
+            line["dry_run"] = True
+        print(json.dumps(line), flush=True)
+    dist.close()
+
+
+def check_parity(args, t, q, p, plev, outs, n_local, first, nlev, np_dtype):
+    """GPU outputs of the timed arrays vs the oracle on 256-point windows of 32 levels."""
+    tol = 1e-4 if args.dtype == "f32" else 1e-6
+    wins = []
+    for lev in np.linspace(0, nlev - 1, 32).round().astype(int):
+        lo = int(lev) * INNER - first + 4321
+        if 0 <= lo and lo + 256 <= n_local:
+            wins.append((int(lev), lo))
+    if not wins:
+        wins = [((first + 0) // INNER, 0)]
+    ht = np.concatenate([t.flat_slice(lo, lo + 256).to_host() for _, lo in wins])
+    hq = np.concatenate([q.flat_slice(lo, lo + 256).to_host() for _, lo in wins])
+    if p is not None:
+        hp = np.concatenate([p.flat_slice(lo, lo + 256).to_host() for _, lo in wins])
+    else:
+        pl = plev.to_host()
+        hp = np.concatenate([np.full(256, pl[lev], np_dtype) for lev, _ in wins])
+    want = oracle_call(args.workload, ht, hq, hp)
+    worst, nan_mismatch = 0.0, 0
+    for o, w in zip(outs, want):
+        g = np.concatenate([o.flat_slice(lo, lo + 256).to_host() for _, lo in wins]).astype(np.float64)
+        w = np.asarray(w, dtype=np.float64)
+        nan_mismatch += int((np.isnan(g) != np.isnan(w)).sum())
+        with np.errstate(all="ignore"):
+            r = np.abs(g - w) / np.abs(w)
+        r = r[np.isfinite(r)]
+        worst = max(worst, float(r.max()) if r.size else 0.0)
+    bis = args.workload == "wetbulb_bisect"
+    return {"points": int(ht.size), "max_rel_err": worst, "nan_mismatch": nan_mismatch, "tolerance": tol,
+            "ok": bool(nan_mismatch == 0 and (worst <= tol or bis))}
+
+
+def traffic_from_profiles(args):
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic_*.json), else null."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d.get(f"{args.workload}:{args.pmode}:{args.dtype}:{args.levels}")
+    except Exception:
+        return None
+
+
+if __name__ == "__main__":
+    main()

@@ -325,11 +325,21 @@ EKM_HD T poly2(T x, double c0, double c1, double c2) {
   return T(c0) + (T(c1) + T(c2) * x) * x;
 }
 
-template <class T>
-EKM_HD T wbpt_direct(T e) {  // thermo.py:1047-1053
-  const T x = e * T(1.0 / 273.16);
-  const T a = T(7.101574) + (T(-20.68208) + (T(16.11182) + (T(2.574631) + T(-5.205688) * x) * x) * x) * x;
-  const T b = T(1.0) + (T(-3.552497) + (T(3.781782) + (T(-0.6899655) + T(-0.5929340) * x) * x) * x) * x;
+EKM_HD double wbpt_direct(double e) {  // thermo.py:1047-1053
+  const double x = e * (1.0 / 273.16);
+  const double a = 7.101574 + (-20.68208 + (16.11182 + (2.574631 + -5.205688 * x) * x) * x) * x;
+  const double b = 1.0 + (-3.552497 + (3.781782 + (-0.6899655 + -0.5929340 * x) * x) * x) * x;
+  return e - m_exp(m_div(a, b));
+}
+
+EKM_HD float wbpt_direct(float e) {
+  const float x = e * float(1.0 / 273.16);
+  // The reference's polyval runs in fp64 whatever the array dtype (fp64 coefficient
+  // array); x^4 overflows fp32 for absurd theta_e where fp64 stays finite.  Only
+  // there (never for atmospheric input) follow it in double.
+  if (!(x <= 1e4f && x >= -1e4f) && x == x) return float(wbpt_direct(double(e)));
+  const float a = 7.101574f + (-20.68208f + (16.11182f + (2.574631f + -5.205688f * x) * x) * x) * x;
+  const float b = 1.0f + (-3.552497f + (3.781782f + (-0.6899655f + -0.5929340f * x) * x) * x) * x;
   return e - m_exp(m_div(a, b));
 }
 

@@ -11,6 +11,14 @@ relative).  The reference's own tests use rtol=1e-3 for wet-bulb for this
 reason (tests/thermo/test_thermo.py:802 there).  For bisect outputs the bar is
 therefore: every point within 2 quanta, and at most `BISECT_FLIP_FRACTION` of
 the points off by more than the plain tolerance.
+
+At exactly saturated points (t == tw) the residual of the very first steps is
+~0 and its sign is pure rounding noise; one early flip can send the search into
+the p - es < eps region where it turns NaN for good.  The reference's own fp32
+and fp64 outputs disagree there (NaN vs 313.16 K on row 431 of its 480-row
+table).  Such reference-unstable points -- identified from the reference's own
+fp32-vs-fp64 disagreement, never from our output -- are excluded from the
+bisect comparison and counted.
 """
 import numpy as np
 
@@ -42,8 +50,22 @@ def assert_same_nonfinite(got, want, what):
     assert np.array_equal(got[inf_w], want[inf_w]), f"{what}: inf signs differ"
 
 
-def assert_parity(got, want, tag, what, bisect=False, rtol=None):
+def bisect_unstable(ref32, ref64):
+    """Points where the reference disagrees with itself across precisions: NaN-ness, or a
+    different sign sequence (results half a quantum or more apart)."""
+    a = np.asarray(ref32, dtype=np.float64)
+    b = np.asarray(ref64, dtype=np.float64)
+    with np.errstate(all="ignore"):
+        return (np.isnan(a) != np.isnan(b)) | (np.abs(a - b) > 0.5 * BISECT_QUANTUM)
+
+
+def assert_parity(got, want, tag, what, bisect=False, rtol=None, unstable=None):
     rtol = RTOL[tag] if rtol is None else rtol
+    if bisect and unstable is not None and unstable.any():
+        assert unstable.mean() <= 0.05, f"{what}: {unstable.sum()} reference-unstable points"
+        keep = ~np.asarray(unstable).ravel()
+        got = np.asarray(got).ravel()[keep]
+        want = np.asarray(want).ravel()[keep]
     assert_same_nonfinite(got, want, what)
     r = rel_err(got, want)
     if not bisect:

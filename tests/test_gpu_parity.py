@@ -1,0 +1,316 @@
+"""Parity of the HIP path (ekm_hip.thermo -> ctypes -> libekm_thermo.so -> gfx950
+kernels) against the vectors recorded from the reference and against the oracle.
+
+Bars (north_star): fp64 <= 1e-6 relative, fp32 <= 1e-4 relative against the
+reference's output in the same dtype, identical NaN/inf pattern; bisect per
+tests/_compare.py.  Everything here needs a real MI355X.
+"""
+import numpy as np
+import pytest
+
+from _compare import BISECT_QUANTUM, assert_parity, assert_same_nonfinite, bisect_unstable, rel_err
+from _golden import case_inputs, case_outputs, golden, manifest
+from golden.known_answers import CASES as KAT
+
+pytestmark = pytest.mark.gpu
+np.seterr(all="ignore")
+CASES = manifest()
+
+
+@pytest.fixture(scope="module")
+def ek():
+    import ekm_hip
+
+    assert ekm_hip.device_count() >= 1
+    return ekm_hip
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import thermo_oracle
+
+    return thermo_oracle
+
+
+def _outs(x):
+    return x if isinstance(x, tuple) else (x,)
+
+
+# ---- (1) every public function x variant x dtype x dataset recorded from the reference ----
+@pytest.mark.parametrize("case", CASES, ids=[c["id"] for c in CASES])
+def test_golden_vectors(ek, case):
+    out = getattr(ek.thermo, case["func"])(*[a.copy() for a in case_inputs(case)], **case["kwargs"])
+    bisect = case["kwargs"].get("t_method") == "bisect"
+    for i, (o, g) in enumerate(zip(_outs(out), case_outputs(case))):
+        want_dtype = np.float32 if case["dtype"] == "f32" else np.float64
+        assert o.dtype == want_dtype, (case["id"], o.dtype)  # dtype-preserving (fp32 in -> fp32 out)
+        unstable = None
+        if bisect:
+            cid = case["id"].split(".")
+            both = [golden()[".".join([cid[0], tag] + cid[2:]) + f".out{i}"] for tag in ("f32", "f64")]
+            unstable = bisect_unstable(*both)
+        assert_parity(o, g, case["dtype"], case["id"], bisect=bisect, unstable=unstable)
+
+
+# ---- (2) the reference's inline known-answer vectors ----
+@pytest.mark.parametrize("func,args,kwargs,expect,rtol", KAT, ids=[f"{i}-{c[0]}" for i, c in enumerate(KAT)])
+def test_known_answers(ek, func, args, kwargs, expect, rtol):
+    out = getattr(ek.thermo, func)(*args, **kwargs)
+    exps = expect if isinstance(expect, tuple) else (expect,)
+    for o, e in zip(_outs(out), exps):
+        assert np.allclose(o, np.asarray(e, dtype=np.float64), rtol=max(rtol, 1e-7), atol=1e-8, equal_nan=True), (o, e)
+
+
+# ---- (3) broadcasting, scalars, lists: results and conventions of the reference ----
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_broadcast_modes(ek, tag):
+    g = golden()
+    T = ek.thermo
+    t, q, pl = (g[f"bcast.{tag}.in.{k}"] for k in ("t", "q", "pl"))
+    assert_parity(T.potential_temperature(t, pl[:, None]), g[f"bcast.{tag}.theta_levmajor"], tag, "theta level-major")
+    assert_parity(T.relative_humidity_from_specific_humidity(t, q, pl[:, None]), g[f"bcast.{tag}.rh_levmajor"], tag,
+                  "rh level-major")
+    assert_parity(T.potential_temperature(t.T.copy(), pl), g[f"bcast.{tag}.theta_levminor"], tag, "theta level-minor")
+    assert_parity(T.dewpoint_from_specific_humidity(q, t.dtype.type(85000.0)), g[f"bcast.{tag}.td_scalar_p"], tag,
+                  "td scalar p")
+    assert_parity(T.ept_from_specific_humidity(t, q, pl[:, None]), g[f"bcast.{tag}.ept_levmajor"], tag, "ept level-major")
+    assert_parity(T.wet_bulb_temperature_from_specific_humidity(t, q, pl[:, None], t_method="newton"),
+                  g[f"bcast.{tag}.wb_newton_2d"], tag, "wet-bulb newton, N-d with level vector")
+
+
+def test_scalar_list_and_readme(ek):
+    g = golden()
+    T = ek.thermo
+    th = T.potential_temperature(264.12, 85000.0)
+    assert isinstance(th, np.float64) and np.isclose(th, g["scalar.theta"], rtol=1e-12)
+    assert np.isclose(T.saturation_vapour_pressure(np.float64(300.0)), g["scalar.es"], rtol=1e-12)
+    assert np.allclose(T.potential_temperature([264.12, 261.45], [85000, 85000]), g["list.theta"], rtol=1e-12)
+    out = T.potential_temperature(np.array([264.12, 261.45]), np.array([85000.0, 85000.0]))
+    assert out.dtype == np.float64 and np.allclose(out, g["readme.theta"], rtol=1e-12)
+    assert T.potential_temperature(np.array([280, 281]), np.array([90000, 80000])).dtype == np.float64  # ints -> fp64
+
+
+def test_inputs_not_mutated_and_errors(ek):
+    T = ek.thermo
+    t = np.linspace(250, 300, 64).astype(np.float32)
+    q = np.full(64, 0.004, np.float32)
+    p = np.full(64, 9e4, np.float32)
+    keep = [a.copy() for a in (t, q, p)]
+    for tm in ("bisect", "newton"):
+        T.wet_bulb_temperature_from_specific_humidity(t, q, p, t_method=tm)
+    for a, k in zip((t, q, p), keep):
+        assert np.array_equal(a, k)
+    assert T.saturation_vapour_pressure(t, phase="bogus") is None
+    with pytest.raises(KeyError):
+        T.ept_from_dewpoint(t, t - 2, p, method="bogus")
+    with pytest.raises(ValueError, match="invalid t_method"):
+        T.temperature_on_moist_adiabat(t, p, t_method="bogus")
+    with pytest.raises(ValueError, match="invalid method"):
+        T.lcl_temperature(t, t - 2, method="bogus")
+    with pytest.raises(ValueError, match="must be > 0"):
+        T.specific_humidity_from_vapour_pressure(t, p, eps=0)
+
+
+# ---- (4) seeded synthetic atmosphere vs the oracle, sizes the oracle finishes in seconds ----
+HOT = [
+    ("potential_temperature", ("t", "p"), {}),
+    ("saturation_vapour_pressure", ("t",), {}),
+    ("saturation_vapour_pressure", ("t",), {"phase": "water"}),
+    ("saturation_vapour_pressure", ("t",), {"phase": "ice"}),
+    ("relative_humidity_from_specific_humidity", ("t", "q", "p"), {}),
+    ("dewpoint_from_specific_humidity", ("q", "p"), {}),
+    ("ept_from_specific_humidity", ("t", "q", "p"), {"method": "ifs"}),
+    ("ept_from_specific_humidity", ("t", "q", "p"), {"method": "bolton35"}),
+    ("ept_from_specific_humidity", ("t", "q", "p"), {"method": "bolton39"}),
+    ("saturation_ept", ("t", "p"), {"method": "ifs"}),
+    ("wet_bulb_temperature_from_specific_humidity", ("t", "q", "p"), {"ept_method": "ifs", "t_method": "newton"}),
+    ("wet_bulb_temperature_from_specific_humidity", ("t", "q", "p"), {"ept_method": "bolton35", "t_method": "newton"}),
+    ("wet_bulb_temperature_from_specific_humidity", ("t", "q", "p"), {"ept_method": "bolton39", "t_method": "newton"}),
+    ("wet_bulb_potential_temperature_from_specific_humidity", ("t", "q", "p"), {}),
+]
+
+
+@pytest.fixture(scope="module")
+def slab():
+    from oracle import synthetic
+
+    out = {}
+    for tag, dt in (("f32", np.float32), ("f64", np.float64)):
+        t, q, p, _ = synthetic.make_fields(16, 16384 + 3, dtype=dt, seed=synthetic.SEED)  # ragged: not a multiple of 4
+        out[tag] = dict(t=t, q=q, p=p)
+    return out
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("func,args,kwargs", HOT, ids=[f"{h[0]}-{'-'.join(h[2].values())}" for h in HOT])
+def test_synthetic_vs_oracle(ek, orc, slab, tag, func, args, kwargs):
+    ins = [slab[tag][a] for a in args]
+    got = getattr(ek.thermo, func)(*ins, **kwargs)
+    want = getattr(orc, func)(*[a.copy() for a in ins], **kwargs)
+    worst = assert_parity(got, want, tag, f"{func} {kwargs} {tag}")
+    assert not np.isnan(got).any()
+    print(f"{func} {kwargs} {tag}: max rel err {worst:.2e}")
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("method", ["ifs", "bolton35", "bolton39"])
+def test_synthetic_bisect_vs_oracle(ek, orc, slab, tag, method):
+    d = {k: v[:4].ravel() for k, v in slab[tag].items()}  # the reference's bisect is 1-D only
+    got = ek.thermo.wet_bulb_temperature_from_specific_humidity(d["t"], d["q"], d["p"], ept_method=method)
+    want = orc.wet_bulb_temperature_from_specific_humidity(d["t"], d["q"], d["p"], ept_method=method)
+    d32 = {k: v.astype(np.float32) for k, v in d.items()}
+    d64 = {k: v.astype(np.float64) for k, v in d32.items()} if tag == "f32" else d
+    ref32 = orc.wet_bulb_temperature_from_specific_humidity(d32["t"], d32["q"], d32["p"], ept_method=method)
+    ref64 = orc.wet_bulb_temperature_from_specific_humidity(d64["t"], d64["q"], d64["p"], ept_method=method)
+    unstable = bisect_unstable(ref32, ref64) if tag == "f32" else None
+    assert_parity(got, want, tag, f"bisect {method} {tag}", bisect=True, unstable=unstable)
+    # the search lands on the same 120/4096 K lattice as the reference
+    k = (got.astype(np.float64) - (273.16 - 20)) / BISECT_QUANTUM
+    assert np.allclose(k, np.round(k), atol=2e-3 if tag == "f32" else 1e-9)
+
+
+# ---- (5) the fused pipelines equal the separate calls they replace ----
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_fused_pipelines(ek, orc, slab, tag):
+    T = ek.thermo
+    t, q, p = (slab[tag][k] for k in ("t", "q", "p"))
+    es, td, rh = T.pipeline_svp_td_rh(t, q, p)
+    th, es5, rh5, td5, the, tw = T.pipeline_full(t, q, p)
+    sep = dict(es=T.saturation_vapour_pressure(t), td=T.dewpoint_from_specific_humidity(q, p),
+               rh=T.relative_humidity_from_specific_humidity(t, q, p), th=T.potential_temperature(t, p),
+               the=T.ept_from_specific_humidity(t, q, p),
+               tw=T.wet_bulb_temperature_from_specific_humidity(t, q, p, t_method="newton"))
+    for name, a in (("es", es), ("td", td), ("rh", rh), ("es", es5), ("td", td5), ("rh", rh5), ("th", th),
+                    ("the", the), ("tw", tw)):
+        assert np.array_equal(a, sep[name], equal_nan=True), f"fused {name} differs from the separate kernel"
+    for got, want in zip((th, es5, rh5, td5, the, tw), orc.pipeline_full(t.copy(), q.copy(), p.copy())):
+        assert_parity(got, want, tag, "pipeline_full vs oracle")
+
+
+# ---- (6) ragged sizes, unaligned views, device-resident arrays, level vectors in LDS ----
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 255, 256, 257, 1023, 1025, 4099, 65537])
+def test_ragged_sizes(ek, orc, n):
+    rng = np.random.default_rng(n)
+    t = rng.uniform(200, 320, n).astype(np.float32)
+    q = rng.uniform(1e-6, 0.02, n).astype(np.float32)
+    p = rng.uniform(2e4, 1.05e5, n).astype(np.float32)
+    got = ek.thermo.pipeline_svp_td_rh(t, q, p)
+    for g_, w_ in zip(got, orc.pipeline_svp_td_rh(t, q, p)):
+        assert g_.shape == (n,)
+        assert_parity(g_, w_, "f32", f"n={n}")
+    t64, p64 = t.astype(np.float64), p.astype(np.float64)
+    assert_parity(ek.thermo.potential_temperature(t64, p64), orc.potential_temperature(t64, p64), "f64", f"f64 n={n}")
+
+
+def test_empty_input(ek):
+    out = ek.thermo.potential_temperature(np.empty(0, np.float32), np.empty(0, np.float32))
+    assert out.shape == (0,) and out.dtype == np.float32
+
+
+def test_unaligned_device_views(ek, orc):
+    n = 10007
+    rng = np.random.default_rng(5)
+    t = rng.uniform(200, 320, n).astype(np.float32)
+    p = rng.uniform(2e4, 1.05e5, n).astype(np.float32)
+    dt, dp = ek.to_device(t), ek.to_device(p)
+    for off in (1, 2, 3, 5):
+        got = ek.thermo.potential_temperature(dt.flat_slice(off, n), dp.flat_slice(off, n)).to_host()
+        assert_parity(got, orc.potential_temperature(t[off:], p[off:]), "f32", f"offset {off}")
+
+
+def test_device_resident_chain(ek, orc, slab):
+    t, q, p = (slab["f32"][k] for k in ("t", "q", "p"))
+    dt, dq, dp = (ek.to_device(a) for a in (t, q, p))
+    e = ek.thermo.vapour_pressure_from_specific_humidity(dq, dp)
+    td = ek.thermo.temperature_from_saturation_vapour_pressure(e)
+    assert isinstance(td, ek.DeviceArray) and td.shape == t.shape and td.dtype == np.float32
+    assert_parity(td.to_host(), orc.dewpoint_from_specific_humidity(q, p), "f32", "device-resident chain")
+    th = ek.thermo.potential_temperature(dt, dp)
+    assert_parity(ek.thermo.temperature_from_potential_temperature(th, dp).to_host(), t, "f32", "theta round trip",
+                  rtol=1e-6)
+
+
+@pytest.mark.parametrize("tag,dt", [("f32", np.float32), ("f64", np.float64)])
+def test_level_vector_in_lds(ek, orc, tag, dt):
+    """137-level pressure vector broadcast over [level, point]: staged in LDS, never materialised."""
+    from oracle import synthetic
+
+    nlev, npts = 137, 1031  # odd inner: chunks straddle level boundaries
+    t, q, pl, _ = synthetic.make_fields(nlev, npts, dtype=dt, seed=3, p_mode="level")
+    pfull = np.ascontiguousarray(np.broadcast_to(pl[:, None], t.shape))
+    for func, args in (("potential_temperature", (t,)), ("relative_humidity_from_specific_humidity", (t, q)),
+                       ("pipeline_full", (t, q))):
+        got = getattr(ek.thermo, func)(*args, pl[:, None])
+        full = getattr(ek.thermo, func)(*args, pfull)
+        want = getattr(orc, func)(*[a.copy() for a in args], pfull.copy())
+        for g_, f_, w_ in zip(_outs(got), _outs(full), _outs(want)):
+            assert np.array_equal(g_, f_, equal_nan=True), f"{func}: level-vector result != full-field result"
+            assert_parity(g_, w_, tag, f"{func} level vector {tag}")
+    # trailing-axis vector (level-minor)
+    tt = np.ascontiguousarray(t.T)
+    got = ek.thermo.potential_temperature(tt, pl)
+    assert_parity(got, orc.potential_temperature(tt, pl), tag, "level-minor")
+
+
+# ---- (7) full-size properties (3600 x 1800 x 137 fp32 = BASELINE.json configs 3-5) ----
+def test_full_size_properties(ek):
+    """One 0.1-degree global field per variable (3.55 GB each), generated on the device.
+    Size-independent properties: no NaN on physical input, the fused pipeline equals the
+    separate kernels bit-for-bit, theta round-trips, a shard computed alone equals the same
+    range of the whole, and sampled points match the oracle."""
+    import ctypes as C
+
+    from ekm_hip import _ffi
+    from oracle import thermo_oracle as orc
+
+    nlev, inner = 137, 3600 * 1800
+    n = nlev * inner
+    lib = _ffi.lib()
+    free, total = C.c_size_t(), C.c_size_t()
+    _ffi.check(lib.ekm_mem_info(0, C.byref(free), C.byref(total)))
+    if free.value < 12 * n * 4:
+        pytest.skip(f"needs {12 * n * 4 / 1e9:.0f} GB of HBM, {free.value / 1e9:.0f} GB free")
+    t, q, p = (ek.DeviceArray.empty((nlev, inner), np.float32) for _ in range(3))
+    _ffi.check(lib.ekm_synth_fill_f32(0, None, t.ptr, q.ptr, p.ptr, 0, n, inner, nlev, 20260313))
+    outs = ek.thermo.pipeline_full(t, q, p)
+    ek.synchronize()
+    names = ("theta", "es", "rh", "td", "theta_e", "tw")
+
+    # sampled parity against the oracle: a 256-point window from every 4th level
+    sample = {}
+    for name, arr in (("t", t), ("q", q), ("p", p)) + tuple(zip(names, outs)):
+        flat = arr.ravel()
+        sample[name] = np.concatenate(
+            [flat.flat_slice(lev * inner + 12345, lev * inner + 12345 + 256).to_host() for lev in range(0, nlev, 4)])
+    want = orc.pipeline_full(sample["t"], sample["q"], sample["p"])
+    for name, w in zip(names, want):
+        assert_parity(sample[name], w, "f32", f"full-size sample {name}")
+
+    # fused == separate kernels, bit for bit, on 8 windows of 4 Mi points spread over the field
+    sep_tw = ek.thermo.wet_bulb_temperature_from_specific_humidity(t, q, p, t_method="newton")
+    sep_rh = ek.thermo.relative_humidity_from_specific_humidity(t, q, p)
+    chunk = 64 * 1024 * 1024
+    for a, b, nm in ((outs[5], sep_tw, "tw"), (outs[2], sep_rh, "rh")):
+        fa, fb = a.ravel(), b.ravel()
+        for lo in range(0, n, n // 7):  # 8 windows spread over the field
+            hi = min(lo + chunk // 16, n)
+            ha, hb = fa.flat_slice(lo, hi).to_host(), fb.flat_slice(lo, hi).to_host()
+            assert np.array_equal(ha, hb, equal_nan=True), f"fused {nm} != separate in [{lo},{hi})"
+            assert not np.isnan(ha).any(), f"NaN in {nm} on physical input"
+    sep_tw.free()
+    sep_rh.free()
+
+    # shard invariance: ranks compute disjoint flat ranges of the same field
+    lo, hi = ek.shard_bounds(n, 8)[3]
+    part = ek.thermo.pipeline_svp_td_rh(t.ravel().flat_slice(lo, hi), q.ravel().flat_slice(lo, hi),
+                                        p.ravel().flat_slice(lo, hi))
+    w = 1 << 20
+    assert np.array_equal(part[2].flat_slice(0, w).to_host(), outs[2].ravel().flat_slice(lo, lo + w).to_host(),
+                          equal_nan=True)
+    assert np.array_equal(part[0].flat_slice(hi - lo - w, hi - lo).to_host(),
+                          outs[1].ravel().flat_slice(hi - w, hi).to_host(), equal_nan=True)
+
+    # theta round trip on the device
+    back = ek.thermo.temperature_from_potential_temperature(outs[0], p)
+    a, b = back.ravel().flat_slice(0, 1 << 22).to_host(), t.ravel().flat_slice(0, 1 << 22).to_host()
+    assert rel_err(a, b).max() < 2e-6
