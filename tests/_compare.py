@@ -59,7 +59,12 @@ def bisect_unstable(ref32, ref64):
         return (np.isnan(a) != np.isnan(b)) | (np.abs(a - b) > 0.5 * BISECT_QUANTUM)
 
 
-def assert_parity(got, want, tag, what, bisect=False, rtol=None, unstable=None):
+def assert_parity(got, want, tag, what, bisect=False, rtol=None, unstable=None, ref64=None):
+    """`ref64` (fp32 comparisons only): the reference's fp64 result on the same fp32 inputs.  Where
+    the reference's own fp32 output sits delta away from it (an ill-conditioned point of the
+    reference's algorithm, e.g. the Bolton-35 Newton step near p = p0), a differently rounded fp32
+    evaluation cannot be expected closer than a few delta: the bar there is max(rtol, 4*delta), and
+    at most 1e-4 of the points may need it."""
     rtol = RTOL[tag] if rtol is None else rtol
     if bisect and unstable is not None and unstable.any():
         assert unstable.mean() <= 0.05, f"{what}: {unstable.sum()} reference-unstable points"
@@ -68,6 +73,13 @@ def assert_parity(got, want, tag, what, bisect=False, rtol=None, unstable=None):
         want = np.asarray(want).ravel()[keep]
     assert_same_nonfinite(got, want, what)
     r = rel_err(got, want)
+    if not bisect and ref64 is not None:
+        bar = np.maximum(rtol, 4.0 * rel_err(want, ref64))
+        relaxed = int((bar > rtol).sum())
+        assert relaxed <= max(1, 1e-4 * r.size), f"{what}: {relaxed} ill-conditioned points in the reference"
+        bad = r > bar
+        assert not bad.any(), f"{what}: rel err {r[bad].max():.3e} beyond max({rtol:g}, 4*delta) at {np.flatnonzero(bad)[:4]}"
+        return float(r[bar <= rtol].max()) if (bar <= rtol).any() else 0.0
     if not bisect:
         worst = float(r.max()) if r.size else 0.0
         assert worst <= rtol, f"{what}: max rel err {worst:.3e} > {rtol:g} at {int(np.argmax(r))}"

@@ -147,7 +147,8 @@ def test_synthetic_vs_oracle(ek, orc, slab, tag, func, args, kwargs):
     ins = [slab[tag][a] for a in args]
     got = getattr(ek.thermo, func)(*ins, **kwargs)
     want = getattr(orc, func)(*[a.copy() for a in ins], **kwargs)
-    worst = assert_parity(got, want, tag, f"{func} {kwargs} {tag}")
+    ref64 = getattr(orc, func)(*[a.astype(np.float64) for a in ins], **kwargs) if tag == "f32" else None
+    worst = assert_parity(got, want, tag, f"{func} {kwargs} {tag}", ref64=ref64)
     assert not np.isnan(got).any()
     print(f"{func} {kwargs} {tag}: max rel err {worst:.2e}")
 
