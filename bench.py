@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--levels", type=int, default=NLEV, help="levels per field (137 = the named config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 20, help="points per worker for the CPU baseline")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="points per worker for the CPU baseline")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise rendezvous/sharding/reporting without touching a GPU (CI on CPU); value is null")
     ap.add_argument("--blocks-per-cu", type=int, default=0)

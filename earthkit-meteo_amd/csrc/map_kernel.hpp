@@ -57,16 +57,31 @@ struct MapArgs {
   int vec_ok;                    // all field pointers 16-B aligned
 };
 
+#ifndef EKM_NT_LOAD
+#define EKM_NT_LOAD 1
+#endif
+#ifndef EKM_NT_STORE
+#define EKM_NT_STORE 1
+#endif
+
 template <class T>
 __device__ __forceinline__ typename VecOf<T>::type ld_stream(const T* p) {
   typedef typename VecOf<T>::type V;
+#if EKM_NT_LOAD
   return __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+#else
+  return *reinterpret_cast<const V*>(p);
+#endif
 }
 
 template <class T>
 __device__ __forceinline__ void st_stream(T* p, typename VecOf<T>::type v) {
   typedef typename VecOf<T>::type V;
+#if EKM_NT_STORE
   __builtin_nontemporal_store(v, reinterpret_cast<V*>(p));
+#else
+  *reinterpret_cast<V*>(p) = v;
+#endif
 }
 
 // ---- all operands are aligned full fields ----------------------------------

@@ -194,6 +194,11 @@ def main():
     store["list.theta"] = np.asarray(ref.potential_temperature([264.12, 261.45], [85000, 85000]))
     store["readme.theta"] = ref.potential_temperature(np.array([264.12, 261.45]), np.array([85000.0, 85000.0]))
 
+    # call signatures of the 39 public functions (names, order, defaults) as data
+    import inspect
+    sigs = {n: str(inspect.signature(getattr(ref, n))) for n in dir(ref)
+            if not n.startswith("_") and inspect.isfunction(getattr(ref, n)) and n != "array_namespace"}
+    store["signatures"] = np.frombuffer(json.dumps(sigs).encode(), dtype=np.uint8)
     store["manifest"] = np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(HERE, "thermo_golden.npz"), **store)
 

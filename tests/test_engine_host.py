@@ -1,0 +1,103 @@
+"""Host logic of ekm_hip that needs no GPU: operand classification (what is handed to the
+kernels as a field / scalar / level vector), dtype promotion, sharding, error conventions."""
+import numpy as np
+import pytest
+
+from ekm_hip import _engine, _ffi
+from ekm_hip.device import shard_bounds
+
+F, S, MAJ, MIN = _ffi.FIELD, _ffi.SCALAR, _ffi.LEVEL_MAJOR, _ffi.LEVEL_MINOR
+
+
+@pytest.mark.parametrize("shape,out,expect", [
+    ((137, 1800, 3600), (137, 1800, 3600), (F, 0, 0)),
+    ((), (137, 10), (S, 0, 0)),
+    ((1,), (137, 10), (S, 0, 0)),
+    ((1, 1), (137, 10), (S, 0, 0)),
+    ((137, 1, 1), (137, 1800, 3600), (MAJ, 137, 1800 * 3600)),
+    ((137, 1), (137, 10), (MAJ, 137, 10)),
+    ((5, 7, 1), (5, 7, 9), (MAJ, 35, 9)),
+    ((137,), (10, 137), (MIN, 137, 0)),
+    ((1, 137), (10, 137), (MIN, 137, 0)),
+    ((7, 9), (5, 7, 9), (MIN, 63, 0)),
+    ((137, 1), (137, 2), None),          # inner < 4: materialised
+    ((3,), (10, 3), None),               # len < 4: materialised
+    ((5, 1, 9), (5, 7, 9), None),        # hole in the middle: materialised
+    ((1, 7, 1), (5, 7, 9), None),        # middle axis only: materialised
+    ((1,), (1,), (F, 0, 0)),
+])
+def test_classify(shape, out, expect):
+    assert _engine.classify(shape, out) == expect
+
+
+def test_classify_matches_numpy_broadcast_indexing():
+    rng = np.random.default_rng(0)
+    for shape, out in [((6, 1, 1), (6, 4, 5)), ((4, 5), (6, 4, 5)), ((6, 4, 1), (6, 4, 8)), ((8,), (3, 8))]:
+        a = rng.normal(size=shape)
+        full = np.broadcast_to(a.reshape((1,) * (len(out) - a.ndim) + a.shape), out).ravel()
+        mode, ln, inner = _engine.classify(shape, out)
+        i = np.arange(full.size)
+        idx = i // inner if mode == MAJ else i % ln
+        assert np.array_equal(a.ravel()[idx], full)
+
+
+def test_result_dtype_follows_numpy_weak_scalars():
+    f32, f64 = np.float32, np.float64
+    r = _engine._result_dtype
+    assert r([np.zeros(3, f32), 1.5]) == (np.dtype(f32), np.dtype(f32))
+    assert r([np.zeros(3, f32), np.zeros(3, f64)]) == (np.dtype(f64), np.dtype(f64))
+    assert r([np.zeros(3, np.int32), 2]) == (np.dtype(f64), np.dtype(f64))
+    assert r([[1.0, 2.0], 3]) == (np.dtype(f64), np.dtype(f64))
+    assert r([264.12, 85000.0]) == (np.dtype(f64), np.dtype(f64))
+    assert r([np.zeros(3, np.float16), 1.0]) == (np.dtype(np.float16), np.dtype(f32))
+    with pytest.raises(TypeError):
+        r([np.zeros(3, np.complex64)])
+
+
+@pytest.mark.parametrize("n,k", [(887760000, 8), (887760000, 2), (1038240, 4), (17, 4), (0, 3), (5, 8), (16, 1)])
+def test_shard_bounds_partition(n, k):
+    b = shard_bounds(n, k)
+    assert len(b) == k and b[0][0] == 0 and b[-1][1] == n
+    for (lo, hi), (lo2, _) in zip(b, b[1:]):
+        assert hi == lo2 and lo <= hi
+    assert all(lo % 16 == 0 for lo, hi in b if lo < n)  # 64-B aligned shard starts keep the float4 path
+
+
+def test_error_conventions_raise_before_any_gpu_work():
+    from ekm_hip import thermo
+
+    t = np.array([280.0])
+    p = np.array([9e4])
+    assert thermo.saturation_vapour_pressure(t, phase="bogus") is None
+    assert thermo.saturation_vapour_pressure_slope(t, phase="bogus") is None
+    with pytest.raises(KeyError) as ei:
+        thermo.ept_from_dewpoint(t, t - 2, p, method="bogus")
+    assert ei.value.args == ("bogus",)
+    with pytest.raises(ValueError, match="temperature_on_moist_adiabat: invalid t_method=bogus specified!"):
+        thermo.temperature_on_moist_adiabat(t, p, t_method="bogus")
+    with pytest.raises(ValueError, match="temperature_on_moist_adiabat: invalid t_method=direct specified!"):
+        thermo.wet_bulb_temperature_from_dewpoint(t, t - 2, p, t_method="direct")
+    with pytest.raises(ValueError, match="lcl_temperature: invalid method=bogus specified!"):
+        thermo.lcl(t, t - 2, p, method="bogus")
+    for f, args in ((thermo.specific_humidity_from_vapour_pressure, (t, p)),
+                    (thermo.mixing_ratio_from_vapour_pressure, (t, p)),
+                    (thermo.saturation_mixing_ratio_slope, (t, p)),
+                    (thermo.saturation_specific_humidity_slope, (t, p))):
+        with pytest.raises(ValueError, match=r"\(\): eps=-1 must be > 0"):
+            f(*args, eps=-1)
+
+
+def test_signatures_match_the_reference():
+    """Names, argument order and defaults of the 39 reference functions."""
+    import inspect
+    import json
+
+    from _golden import golden
+    from ekm_hip import thermo
+    from oracle import thermo_oracle as orc
+
+    sigs = json.loads(bytes(golden()["signatures"]).decode())  # recorded from the reference by gen_golden.py
+    assert sorted(sigs) == sorted(orc.ALL_FUNCTIONS) and len(sigs) == 39
+    for name, sig in sigs.items():
+        assert str(inspect.signature(getattr(thermo, name))) == sig, name
+        assert str(inspect.signature(getattr(orc, name))) == sig, name

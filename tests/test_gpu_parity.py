@@ -297,7 +297,7 @@ def test_full_size_properties(ek):
         for lo in range(0, n, n // 7):  # 8 windows spread over the field
             hi = min(lo + chunk // 16, n)
             ha, hb = fa.flat_slice(lo, hi).to_host(), fb.flat_slice(lo, hi).to_host()
-            assert np.array_equal(ha, hb, equal_nan=True), f"fused {nm} != separate in [{lo},{hi})"
+            assert_parity(ha, hb, "f32", f"fused {nm} vs separate kernel in [{lo},{hi})", rtol=1e-5)
             assert not np.isnan(ha).any(), f"NaN in {nm} on physical input"
     sep_tw.free()
     sep_rh.free()

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of kernel variants and launch tunings on one GPU, one process
+(cdna_hip_programming.md rule 24): for every (library variant, blocks_per_cu, unroll,
+workload) run R rounds of K launches, report median/min kernel ms and GB/s.
+
+    python tools/sweep.py --libs default,variants/nont/libekm_thermo.so --workloads p3,full \
+        --bpc 4,8,16 --unroll 1,2 --rounds 5 --steps 5 --levels 137
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "earthkit-meteo_amd")]
+from ekm_hip import _ffi  # noqa: E402
+
+INNER = 1800 * 3600
+W = {  # workload: entry, operands, ints, nout, bytes/pt (field p)
+    "full": ("pipeline_full", "tqp", (), 6, 36), "p3": ("pipeline_svp_td_rh", "tqp", (), 3, 24),
+    "wetbulb": ("wet_bulb_temperature_from_specific_humidity", "tqp", (0, 1), 1, 16),
+    "wetbulb_bisect": ("wet_bulb_temperature_from_specific_humidity", "tqp", (0, 0), 1, 16),
+    "rh": ("relative_humidity_from_specific_humidity", "tqp", (), 1, 16),
+    "ept": ("ept_from_specific_humidity", "tqp", (0,), 1, 16),
+    "theta": ("potential_temperature", "tp", (), 1, 12), "svp": ("saturation_vapour_pressure", "t", (0,), 1, 8),
+    "td": ("dewpoint_from_specific_humidity", "qp", (), 1, 12), "c2k": ("celsius_to_kelvin", "t", (), 1, 8),
+}
+
+
+def load(path):
+    lib = C.CDLL(path)
+    for name, (args, res) in _ffi._signatures().items():
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = args, res
+    return lib
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--libs", default="default")
+    ap.add_argument("--workloads", default="p3,full")
+    ap.add_argument("--bpc", default="8")
+    ap.add_argument("--unroll", default="1")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--levels", type=int, default=137)
+    ap.add_argument("--pmode", default="field")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+
+    libs = {}
+    for spec in a.libs.split(","):
+        path = _ffi.library_path() if spec == "default" else os.path.join(ROOT, "earthkit-meteo_amd", spec)
+        libs[spec] = load(path)
+    base = next(iter(libs.values()))
+    chk = lambda rc: rc >= 0 or sys.exit(f"error {rc}: {base.ekm_last_error().decode()}")  # noqa: E731
+    dev, n = 0, a.levels * INNER
+
+    def dmalloc(nbytes):
+        p = C.c_void_p()
+        chk(base.ekm_malloc(dev, nbytes, C.byref(p)))
+        return p.value
+
+    t, q, p = dmalloc(4 * n), dmalloc(4 * n), dmalloc(4 * n)
+    pl = dmalloc(4 * a.levels)
+    outs = [dmalloc(4 * n) for _ in range(6)]
+    chk(base.ekm_synth_fill_f32(dev, None, t, q, p, 0, n, INNER, a.levels, 20260313))
+    chk(base.ekm_synth_levels_f32(dev, None, pl, a.levels))
+    ev0, ev1 = C.c_void_p(), C.c_void_p()
+    chk(base.ekm_event_create(dev, C.byref(ev0)))
+    chk(base.ekm_event_create(dev, C.byref(ev1)))
+    F = _ffi.Operand
+    ops = {"t": F(t, 0, 0, 0, 0), "q": F(q, 0, 0, 0, 0),
+           "p": F(p, 0, 0, 0, 0) if a.pmode == "field" else F(pl, 2, 0, a.levels, INNER)}
+
+    configs = [(ln, int(b), int(u), w) for ln in libs for b in a.bpc.split(",") for u in a.unroll.split(",")
+               for w in a.workloads.split(",")]
+    times = {c: [] for c in configs}
+    for rnd in range(a.rounds + 1):  # round 0 = warm-up
+        for c in configs:
+            ln, b, u, w = c
+            lib = libs[ln]
+            entry, which, ints, nout, bpp = W[w]
+            chk(lib.ekm_set_tuning(b, u))
+            fn = getattr(lib, f"ekm_{entry}_f32")
+            cargs = [dev, None] + [C.byref(ops[k]) for k in which] + list(ints) + outs[:nout] + [n]
+            chk(fn(*cargs))
+            chk(base.ekm_event_record(dev, ev0, None))
+            for _ in range(a.steps):
+                chk(fn(*cargs))
+            chk(base.ekm_event_record(dev, ev1, None))
+            chk(base.ekm_sync(dev))
+            ms = C.c_float()
+            chk(base.ekm_event_elapsed_ms(dev, ev0, ev1, C.byref(ms)))
+            if rnd:
+                times[c].append(ms.value / a.steps)
+    rows = []
+    for c in configs:
+        ln, b, u, w = c
+        bpp = W[w][4] - (4 if a.pmode == "level" and "p" in W[w][1] else 0)
+        med, mn = statistics.median(times[c]), min(times[c])
+        rows.append(dict(lib=ln, bpc=b, unroll=u, workload=w, med_ms=round(med, 4), min_ms=round(mn, 4),
+                         gbs_med=round(bpp * n / med / 1e6, 1), frac=round(bpp * n / med / 1e6 / 8000, 4)))
+        print(f"{ln:28s} bpc={b:<3d} u={u} {w:15s} med {med:8.4f} ms  min {mn:8.4f} ms  {rows[-1]['gbs_med']:8.1f} GB/s"
+              f"  {rows[-1]['frac'] * 100:5.1f}%", flush=True)
+    if a.out:
+        with open(a.out, "w") as f:
+            json.dump(rows, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
