@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Condense a rocprofv3 output directory (kernel-trace --stats pass + FETCH_SIZE pass +
+WRITE_SIZE pass, as produced by tools/profile_gpu.sh) into the small files kept under profiles/.
+
+    python tools/summarize_profile.py gpurun_out/prof_r01 profiles/r01_full 'full:field:f32:137'
+
+HBM traffic follows MI355X_MICROARCH.md (HBM / rocprofv3 sections): FETCH_SIZE and WRITE_SIZE are
+in KiB and need separate passes; on gfx950 FETCH_SIZE reports exactly half of a 16-B/lane
+streaming read, so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact for 16-B/lane stores.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def counters(d, which):
+    f = glob.glob(os.path.join(d, f"pmc_{which}", "**", "*_counter_collection.csv"), recursive=True)
+    agg = collections.defaultdict(list)
+    for path in f:
+        for r in csv.DictReader(open(path)):
+            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def main():
+    src, dst, key = sys.argv[1], sys.argv[2], sys.argv[3]
+    os.makedirs(os.path.dirname(dst), exist_ok=True)
+    stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)[0]
+    shutil.copy(stats, dst + "_kernel_stats.csv")
+    fetch = counters(src, "fetch")
+    write = counters(src, "write")
+    rows = list(csv.DictReader(open(stats)))
+    out = {"source": "rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)",
+           "kernels": []}
+    traffic = {}
+    for r in rows:
+        name = r["Name"]
+        if "map_" not in name:
+            continue
+        rd = 2.0 * fetch.get(name, 0.0) * 1024.0
+        wr = write.get(name, 0.0) * 1024.0
+        out["kernels"].append({"name": name, "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                               "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]),
+                               "FETCH_SIZE_KiB_avg": fetch.get(name), "WRITE_SIZE_KiB_avg": write.get(name),
+                               "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr, "hbm_bytes_per_launch": rd + wr,
+                               "GBps_from_pmc_and_avg_ns": (rd + wr) / float(r["AverageNs"])})
+        traffic[key] = rd + wr
+    json.dump(out, open(dst + "_summary.json", "w"), indent=1)
+    lat = os.path.join(os.path.dirname(dst), "traffic_latest.json")
+    cur = json.load(open(lat)) if os.path.exists(lat) else {}
+    cur.update(traffic)
+    json.dump(cur, open(lat, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
