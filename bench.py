@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="points per worker for the CPU baseline")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise rendezvous/sharding/reporting without touching a GPU (CI on CPU); value is null")
-    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--tiles", type=int, default=0)
     ap.add_argument("--unroll", type=int, default=0)
     return ap.parse_args()
 
@@ -215,8 +215,8 @@ def main():
         ndev = ekm_hip.device_count()
         dev = dist.local_rank % ndev
         ekm_hip.set_device(dev)
-        if args.blocks_per_cu or args.unroll:
-            _ffi.check(lib.ekm_set_tuning(args.blocks_per_cu, args.unroll))
+        if args.tiles or args.unroll:
+            _ffi.check(lib.ekm_set_tuning(args.tiles, args.unroll))
         shape = (n_local,)
         t = DeviceArray.empty(shape, np_dtype, dev)
         q = DeviceArray.empty(shape, np_dtype, dev)

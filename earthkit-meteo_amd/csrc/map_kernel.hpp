@@ -7,9 +7,9 @@
 //  * every input field is read once, every output field written once;
 //  * loads/stores are non-temporal: nothing is re-used, so the streams should
 //    not displace each other in L2 / MALL;
-//  * persistent grid (CUs x blocks_per_cu workgroups) with a grid-stride loop,
-//    UNROLL independent vectors per lane per trip to keep >= 32 KiB of loads in
-//    flight per CU;
+//  * one workgroup per run of `tiles` consecutive 4-KiB tiles (no persistent
+//    grid-stride loop: in-order dispatch keeps one moving window per stream,
+//    measured 10-25 % faster), UNROLL tiles in flight per lane per trip;
 //  * operands that are not full fields (a scalar, or a level vector such as the
 //    137 model-level pressures) never touch HBM per point: the vector is staged
 //    once per workgroup into LDS and indexed by level, with the level index
@@ -52,8 +52,8 @@ struct MapArgs {
   unsigned len[NIN];             // vector length for the LEVEL modes
   unsigned lds_off[NIN];         // element offset of the staged vector in LDS
   unsigned long long inner[NIN]; // LEVEL_MAJOR: points per level
-  unsigned long long step_q[NIN];  // (grid stride in elements) / inner   resp. unused
-  unsigned long long step_r[NIN];  // (grid stride in elements) % inner   resp. % len
+  unsigned long long step_q[NIN];  // (elements per tile) / inner   resp. unused
+  unsigned long long step_r[NIN];  // (elements per tile) % inner   resp. % len
   int vec_ok;                    // all field pointers 16-B aligned
 };
 
@@ -85,54 +85,48 @@ __device__ __forceinline__ void st_stream(T* p, typename VecOf<T>::type v) {
 }
 
 // ---- all operands are aligned full fields ----------------------------------
+// Workgroup b owns `tiles` consecutive tiles of 256 vectors (256 x 16 B = 4 KiB per
+// stream per tile) and exits: the dispatcher hands out workgroups in order, so at any
+// moment the chip reads and writes one moving window of each stream.  Measured on
+// MI355X this beats a persistent grid-stride loop by 10-25 % (profiles/).
 template <class Op, class T, int UNROLL>
-__global__ __launch_bounds__(kThreads) void map_fields(const MapArgs<T, Op::NIN, Op::NOUT> a) {
+__global__ __launch_bounds__(kThreads) void map_fields(const MapArgs<T, Op::NIN, Op::NOUT> a, unsigned tiles) {
   constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N;
   typedef typename VecOf<T>::type Vec;
   const unsigned long long nvec = a.n / V;
-  const unsigned long long stride = (unsigned long long)gridDim.x * kThreads;
-  unsigned long long v = (unsigned long long)blockIdx.x * kThreads + threadIdx.x;
+  const unsigned long long base = (unsigned long long)blockIdx.x * tiles * kThreads + threadIdx.x;
 
-  for (; v + (UNROLL - 1) * stride < nvec; v += UNROLL * stride) {
+  for (unsigned k = 0; k < tiles; k += UNROLL) {
+    const unsigned long long v0 = base + (unsigned long long)k * kThreads;
     Vec xin[UNROLL][NIN];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u)
+    for (int u = 0; u < UNROLL; ++u) {
+      const unsigned long long v = v0 + u * kThreads;
+      if (v < nvec) {
 #pragma unroll
-      for (int i = 0; i < NIN; ++i) xin[u][i] = ld_stream<T>(a.in[i] + (v + u * stride) * V);
+        for (int i = 0; i < NIN; ++i) xin[u][i] = ld_stream<T>(a.in[i] + v * V);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      Vec yout[NOUT];
+      const unsigned long long v = v0 + u * kThreads;
+      if (v < nvec) {
+        Vec yout[NOUT];
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        T x[NIN], y[NOUT];
+        for (int j = 0; j < V; ++j) {
+          T x[NIN], y[NOUT];
 #pragma unroll
-        for (int i = 0; i < NIN; ++i) x[i] = xin[u][i][j];
-        Op::template apply<T>(x, y, a.rp);
+          for (int i = 0; i < NIN; ++i) x[i] = xin[u][i][j];
+          Op::template apply<T>(x, y, a.rp);
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) yout[o][j] = y[o];
+          for (int o = 0; o < NOUT; ++o) yout[o][j] = y[o];
+        }
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) st_stream<T>(a.out[o] + v * V, yout[o]);
       }
-#pragma unroll
-      for (int o = 0; o < NOUT; ++o) st_stream<T>(a.out[o] + (v + u * stride) * V, yout[o]);
     }
   }
-  // remaining whole vectors (fewer than UNROLL per lane)
-  for (; v < nvec; v += stride) {
-    Vec xin[NIN], yout[NOUT];
-#pragma unroll
-    for (int i = 0; i < NIN; ++i) xin[i] = ld_stream<T>(a.in[i] + v * V);
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      T x[NIN], y[NOUT];
-#pragma unroll
-      for (int i = 0; i < NIN; ++i) x[i] = xin[i][j];
-      Op::template apply<T>(x, y, a.rp);
-#pragma unroll
-      for (int o = 0; o < NOUT; ++o) yout[o][j] = y[o];
-    }
-#pragma unroll
-    for (int o = 0; o < NOUT; ++o) st_stream<T>(a.out[o] + v * V, yout[o]);
-  }
-  // ragged tail: n % V single elements
+  // ragged tail: n % V single elements, done by the first lanes of workgroup 0
   const unsigned long long e = nvec * V + (unsigned long long)blockIdx.x * kThreads + threadIdx.x;
   if (e < a.n) {
     T x[NIN], y[NOUT];
@@ -148,7 +142,7 @@ __global__ __launch_bounds__(kThreads) void map_fields(const MapArgs<T, Op::NIN,
 extern __shared__ __align__(16) unsigned char ekm_lds_raw[];
 
 template <class Op, class T>
-__global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, Op::NOUT> a) {
+__global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, Op::NOUT> a, unsigned tiles) {
   constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N;
   typedef typename VecOf<T>::type Vec;
   T* lds = reinterpret_cast<T*>(ekm_lds_raw);
@@ -165,85 +159,93 @@ __global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, 
   __syncthreads();
 
   const unsigned long long nchunk = (a.n + V - 1) / V;  // last chunk may be partial
-  const unsigned long long stride = (unsigned long long)gridDim.x * kThreads;
-  unsigned long long c = (unsigned long long)blockIdx.x * kThreads + threadIdx.x;
+  const unsigned long long cblock = (unsigned long long)blockIdx.x * tiles * kThreads;  // wave-uniform
 
-  // per-operand running position of element c*V: (level, offset in level) or index
+  // Position of this lane's first chunk in every level operand: one division per workgroup
+  // on the scalar unit (cblock is uniform), then carried forward by one tile per trip.
   unsigned long long pos_q[NIN], pos_r[NIN];
 #pragma unroll
   for (int i = 0; i < NIN; ++i) {
     pos_q[i] = 0;
     pos_r[i] = 0;
     if (a.mode[i] == EKM_LEVEL_MAJOR) {
-      pos_q[i] = (c * V) / a.inner[i];
-      pos_r[i] = (c * V) % a.inner[i];
+      const unsigned long long e = cblock * V;
+      pos_q[i] = e / a.inner[i];
+      pos_r[i] = e % a.inner[i] + (unsigned long long)threadIdx.x * V;
+      while (pos_r[i] >= a.inner[i]) {
+        pos_r[i] -= a.inner[i];
+        pos_q[i] += 1;
+      }
     } else if (a.mode[i] == EKM_LEVEL_MINOR) {
-      pos_r[i] = (c * V) % a.len[i];
+      pos_r[i] = ((cblock * V) % a.len[i] + (unsigned long long)threadIdx.x * V) % a.len[i];
     }
   }
 
-  for (; c < nchunk; c += stride) {
-    const unsigned long long e0 = c * V;
-    const bool full = (e0 + V <= a.n);
-    Vec xin[NIN];
+  for (unsigned k = 0; k < tiles; ++k) {
+    const unsigned long long c = cblock + (unsigned long long)k * kThreads + threadIdx.x;
+    if (c < nchunk) {
+      const unsigned long long e0 = c * V;
+      const bool full = (e0 + V <= a.n);
+      Vec xin[NIN];
 #pragma unroll
-    for (int i = 0; i < NIN; ++i) {
-      if (a.mode[i] == EKM_FIELD) {
+      for (int i = 0; i < NIN; ++i) {
+        if (a.mode[i] == EKM_FIELD) {
+          if (full && a.vec_ok) {
+            xin[i] = ld_stream<T>(a.in[i] + e0);
+          } else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) xin[i][j] = (e0 + j < a.n) ? a.in[i][e0 + j] : T(1);
+          }
+        } else if (a.mode[i] == EKM_SCALAR) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) xin[i][j] = sval[i];
+        } else if (a.mode[i] == EKM_LEVEL_MAJOR) {
+          const T* tab = lds + a.lds_off[i];
+          const unsigned long long l = pos_q[i], r = pos_r[i], inn = a.inner[i];
+          const T v0 = tab[l];
+          if (r + V <= inn) {  // whole chunk inside one level (the usual case)
+#pragma unroll
+            for (int j = 0; j < V; ++j) xin[i][j] = v0;
+          } else {
+            const unsigned last = a.len[i] - 1;
+            const unsigned l1 = (l + 1 <= last) ? (unsigned)(l + 1) : last;
+            const T v1 = tab[l1];  // inner >= V (host-checked): at most one boundary per chunk
+#pragma unroll
+            for (int j = 0; j < V; ++j) xin[i][j] = (r + j < inn) ? v0 : v1;
+          }
+        } else {  // EKM_LEVEL_MINOR, len >= V (host-checked)
+          const T* tab = lds + a.lds_off[i];
+          const unsigned len = a.len[i];
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            unsigned idx = (unsigned)pos_r[i] + j;
+            if (idx >= len) idx -= len;
+            xin[i][j] = tab[idx];
+          }
+        }
+      }
+      Vec yout[NOUT];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        T x[NIN], y[NOUT];
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) x[i] = xin[i][j];
+        Op::template apply<T>(x, y, a.rp);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) yout[o][j] = y[o];
+      }
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) {
         if (full && a.vec_ok) {
-          xin[i] = ld_stream<T>(a.in[i] + e0);
+          st_stream<T>(a.out[o] + e0, yout[o]);
         } else {
 #pragma unroll
-          for (int j = 0; j < V; ++j) xin[i][j] = (e0 + j < a.n) ? a.in[i][e0 + j] : T(1);
-        }
-      } else if (a.mode[i] == EKM_SCALAR) {
-#pragma unroll
-        for (int j = 0; j < V; ++j) xin[i][j] = sval[i];
-      } else if (a.mode[i] == EKM_LEVEL_MAJOR) {
-        const T* tab = lds + a.lds_off[i];
-        const unsigned long long l = pos_q[i], r = pos_r[i], inn = a.inner[i];
-        const T v0 = tab[l];
-        if (r + V <= inn) {  // whole chunk inside one level (the usual case)
-#pragma unroll
-          for (int j = 0; j < V; ++j) xin[i][j] = v0;
-        } else {
-          const unsigned last = a.len[i] - 1;
-          const unsigned l1 = (l + 1 <= last) ? (unsigned)(l + 1) : last;
-          const T v1 = tab[l1];  // inner >= V (host-checked): at most one boundary per chunk
-#pragma unroll
-          for (int j = 0; j < V; ++j) xin[i][j] = (r + j < inn) ? v0 : v1;
-        }
-      } else {  // EKM_LEVEL_MINOR, len >= V (host-checked)
-        const T* tab = lds + a.lds_off[i];
-        const unsigned len = a.len[i];
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-          unsigned idx = (unsigned)pos_r[i] + j;
-          if (idx >= len) idx -= len;
-          xin[i][j] = tab[idx];
+          for (int j = 0; j < V; ++j)
+            if (e0 + j < a.n) a.out[o][e0 + j] = yout[o][j];
         }
       }
     }
-    Vec yout[NOUT];
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      T x[NIN], y[NOUT];
-#pragma unroll
-      for (int i = 0; i < NIN; ++i) x[i] = xin[i][j];
-      Op::template apply<T>(x, y, a.rp);
-#pragma unroll
-      for (int o = 0; o < NOUT; ++o) yout[o][j] = y[o];
-    }
-#pragma unroll
-    for (int o = 0; o < NOUT; ++o) {
-      if (full && a.vec_ok) {
-        st_stream<T>(a.out[o] + e0, yout[o]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < V; ++j)
-          if (e0 + j < a.n) a.out[o][e0 + j] = yout[o][j];
-      }
-    }
-    // advance the running positions by one grid stride
+    // advance the running positions by one tile (kThreads * V elements)
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
       if (a.mode[i] == EKM_LEVEL_MAJOR) {
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, 
 int set_error(int code, const char* fmt, ...);
 int device_cus(int dev);            // CU count of device `dev` (cached), <0 on error
 int use_device(int dev);            // hipSetDevice with error capture
-int tuning_blocks_per_cu();
+int tuning_tiles_per_block();
 int tuning_unroll();
 
 constexpr unsigned kMaxLdsBytes = 64 * 1024;
@@ -276,9 +278,6 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
   if (n == 0) return EKM_OK;
   int rc = use_device(dev);
   if (rc != EKM_OK) return rc;
-  const int cus = device_cus(dev);
-  if (cus <= 0) return cus;
-
   MapArgs<T, NIN, NOUT> a;
   a.n = n;
   a.rp = T(rp);
@@ -338,18 +337,22 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
                      kMaxLdsBytes);
 
   const unsigned long long nchunk = (n + V - 1) / V;
-  const unsigned long long want = (nchunk + kThreads - 1) / kThreads;
-  const unsigned long long cap = (unsigned long long)cus * tuning_blocks_per_cu();
-  const unsigned grid = (unsigned)(want < cap ? want : cap);
+  const unsigned long long ntile = (nchunk + kThreads - 1) / kThreads;
+  unsigned tiles = (unsigned)tuning_tiles_per_block();
+  const int unroll = tuning_unroll();
+  if (!bc && aligned && unroll >= 2) tiles = (tiles + 1u) & ~1u;  // the unrolled body takes tiles in pairs
+  // keep the grid within the launch limit for very large fields
+  while ((ntile + tiles - 1) / tiles > 0x7fffffffull) tiles *= 2;
+  const unsigned grid = (unsigned)((ntile + tiles - 1) / tiles);
   hipStream_t s = static_cast<hipStream_t>(stream);
 
   if (!bc && aligned) {
-    if (tuning_unroll() >= 2)
-      hipLaunchKernelGGL((map_fields<Op, T, 2>), dim3(grid), dim3(kThreads), 0, s, a);
+    if (unroll >= 2)
+      hipLaunchKernelGGL((map_fields<Op, T, 2>), dim3(grid), dim3(kThreads), 0, s, a, tiles);
     else
-      hipLaunchKernelGGL((map_fields<Op, T, 1>), dim3(grid), dim3(kThreads), 0, s, a);
+      hipLaunchKernelGGL((map_fields<Op, T, 1>), dim3(grid), dim3(kThreads), 0, s, a, tiles);
   } else {
-    const unsigned long long step = (unsigned long long)grid * kThreads * V;
+    const unsigned long long step = (unsigned long long)kThreads * V;  // elements per tile
     for (int i = 0; i < NIN; ++i) {
       if (a.mode[i] == EKM_LEVEL_MAJOR) {
         a.step_q[i] = step / a.inner[i];
@@ -358,7 +361,7 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
         a.step_r[i] = step % a.len[i];
       }
     }
-    hipLaunchKernelGGL((map_bcast<Op, T>), dim3(grid), dim3(kThreads), lds_elems * sizeof(T), s, a);
+    hipLaunchKernelGGL((map_bcast<Op, T>), dim3(grid), dim3(kThreads), lds_elems * sizeof(T), s, a, tiles);
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return set_error(EKM_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));

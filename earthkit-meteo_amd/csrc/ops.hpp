@@ -127,18 +127,19 @@ struct OpPipelineFull {
   template <class T>
   EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T) {
     const T t = x[0], q = x[1], p = x[2];
-    const T th = theta(t, p);
-    const T es = es_mixed(t);
-    const T e = e_from_q(q, p);
-    const T td = t_from_es(e);
-    const T tl = lcl_t<LCL_DAVIES>(t, td);
-    const T the = th * m_exp(m_div(T(k::K0_ifs) * q, tl));
+    const PTerms<T> P = pterms(p);
+    const T th = t * P.thf;                           // thermo.py:829
+    const T es = es_mixed(t);                         // es_comp.py:141-166
+    const T e = e_from_q(q, p);                       // thermo.py:130-131
+    const T td = t_from_es(e);                        // es_comp.py:128-130
+    const T tl = lcl_t<LCL_DAVIES>(t, td);            // thermo.py:961
+    const T the = th * m_exp2(T(k::K0_ifs * k::LOG2E) * q * m_rcp(tl));  // thermo.py:1175
     y[0] = th;
     y[1] = es;
-    y[2] = m_div(T(100.0) * e, es);
+    y[2] = T(100.0) * e * m_rcp(es);                  // thermo.py:556
     y[3] = td;
     y[4] = the;
-    y[5] = t_on_ma_newton<EPT_IFS>(the, p);
+    y[5] = t_on_ma_newton_ifs(the, P);                // thermo.py:1081-1159
   }
 };
 

@@ -39,7 +39,7 @@ constexpr int kMaxDev = 64;
 static int g_ndev = -1;
 static int g_cus[kMaxDev];
 static std::mutex g_mu;
-static std::atomic<int> g_blocks_per_cu{8};
+static std::atomic<int> g_tiles_per_block{1};
 static std::atomic<int> g_unroll{1};
 
 static int probe() {
@@ -77,7 +77,7 @@ int device_cus(int dev) {
   return g_cus[dev];
 }
 
-int tuning_blocks_per_cu() { return g_blocks_per_cu.load(std::memory_order_relaxed); }
+int tuning_tiles_per_block() { return g_tiles_per_block.load(std::memory_order_relaxed); }
 int tuning_unroll() { return g_unroll.load(std::memory_order_relaxed); }
 
 // ---- synthetic atmosphere on the device (SURVEY.md 8d distribution) ---------
@@ -335,16 +335,16 @@ int ekm_event_elapsed_ms(int dev, void* start, void* stop, float* ms) {
   return EKM_OK;
 }
 
-int ekm_set_tuning(int blocks_per_cu, int unroll) {
-  if (blocks_per_cu < 0 || blocks_per_cu > 64 || unroll < 0 || unroll > 2)
-    return set_error(EKM_ERR_ARG, "set_tuning: blocks_per_cu in [1,64], unroll in {1,2} (0 keeps)");
-  if (blocks_per_cu) g_blocks_per_cu.store(blocks_per_cu);
+int ekm_set_tuning(int tiles_per_block, int unroll) {
+  if (tiles_per_block < 0 || tiles_per_block > 65536 || unroll < 0 || unroll > 2)
+    return set_error(EKM_ERR_ARG, "set_tuning: tiles_per_block in [1,65536], unroll in {1,2} (0 keeps)");
+  if (tiles_per_block) g_tiles_per_block.store(tiles_per_block);
   if (unroll) g_unroll.store(unroll);
   return EKM_OK;
 }
 
-int ekm_get_tuning(int* blocks_per_cu, int* unroll) {
-  if (blocks_per_cu) *blocks_per_cu = g_blocks_per_cu.load();
+int ekm_get_tuning(int* tiles_per_block, int* unroll) {
+  if (tiles_per_block) *tiles_per_block = g_tiles_per_block.load();
   if (unroll) *unroll = g_unroll.load();
   return EKM_OK;
 }

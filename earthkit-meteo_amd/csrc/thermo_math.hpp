@@ -99,55 +99,79 @@ EKM_HD T m_sign(T x) {
   return x > T(0) ? T(1) : (x < T(0) ? T(-1) : (x == T(0) ? T(0) : x));
 }
 
+// Wave-uniform "does any lane need this?" test.  On the device it is a ballot, i.e. a
+// scalar branch the whole wave takes or skips together (no divergence cost, and whole
+// waves of warm-only / cold-only / non-regime points skip work); on the host it is the
+// plain per-point condition.  Purely an execution shortcut: lanes that need a value
+// always get it computed.
+#if defined(EKM_NO_WAVE_SKIP)
+#define EKM_ANY(cond) (true)
+#elif defined(__HIP_DEVICE_COMPILE__)
+#define EKM_ANY(cond) (__builtin_amdgcn_ballot_w64(cond) != 0ull)
+#else
+#define EKM_ANY(cond) (cond)
+#endif
+
 // ---- saturation vapour pressure (es_comp.py) -------------------------------
+// es = C1*exp(C3*(t-T0)/(t-C4)) evaluated as exp2(fma((t-T0)*rcp(t-C4), C3*log2(e), log2(C1))):
+// one rcp + one exp2 on the transcendental unit, constants folded in double.
+namespace k {
+constexpr double LOG2E = 1.4426950408889634074;
+constexpr double LN2 = 0.69314718055994530942;
+constexpr double LOG2_C1 = 9.25552433725897;  // log2(611.21)
+}  // namespace k
+
 template <class T>
 EKM_HD T es_water(T t) {  // es_comp.py:133-134
-  return T(k::C1) * m_exp(m_div(T(k::C3W) * (t - T(k::T0)), t - T(k::C4W)));
+  return m_exp2((t - T(k::T0)) * m_rcp(t - T(k::C4W)) * T(k::C3W * k::LOG2E) + T(k::LOG2_C1));
 }
 
 template <class T>
 EKM_HD T es_ice(T t) {  // es_comp.py:137-138
-  return T(k::C1) * m_exp(m_div(T(k::C3I) * (t - T(k::T0)), t - T(k::C4I)));
+  return m_exp2((t - T(k::T0)) * m_rcp(t - T(k::C4I)) * T(k::C3I * k::LOG2E) + T(k::LOG2_C1));
 }
 
 // es and d(es)/dT for one phase from one reciprocal (es_comp.py:169-174)
 template <class T>
 EKM_HD void es_slope_water(T t, T& es, T& des) {
   const T r = m_rcp(t - T(k::C4W));
-  es = T(k::C1) * m_exp(T(k::C3W) * (t - T(k::T0)) * r);
+  es = m_exp2((t - T(k::T0)) * r * T(k::C3W * k::LOG2E) + T(k::LOG2_C1));
   des = es * T(k::sw) * (r * r);
 }
 
 template <class T>
 EKM_HD void es_slope_ice(T t, T& es, T& des) {
   const T r = m_rcp(t - T(k::C4I));
-  es = T(k::C1) * m_exp(T(k::C3I) * (t - T(k::T0)) * r);
+  es = m_exp2((t - T(k::T0)) * r * T(k::C3I * k::LOG2E) + T(k::LOG2_C1));
   des = es * T(k::si) * (r * r);
 }
 
-// Mixed phase, branch-free (es_comp.py:141-166).  The reference gathers three
-// masks; per point that is: ice at t <= TI, water at t >= T0, alpha-blend in
-// between.  NaN fails both tests and lands in the blend, giving NaN.
+// Mixed phase (es_comp.py:141-166).  The reference gathers three masks; per point that
+// is: ice at t <= TI, water at t >= T0, alpha-blend in between.  NaN fails both tests and
+// lands in the blend, giving NaN.  The water (ice) formula is evaluated only when some
+// lane of the wave is above TI (below T0).
 template <class T>
 EKM_HD T es_mixed(T t) {
-  const T ew = es_water(t);
-  const T ei = es_ice(t);
+  T ew = T(0), ei = T(0);
+  if (EKM_ANY(!(t <= T(k::TI)))) ew = es_water(t);
+  if (EKM_ANY(!(t >= T(k::T0)))) ei = es_ice(t);
   const T a = m_sq((t - T(k::TI)) * T(1.0 / (k::T0 - k::TI)));
-  const T mid = a * ew + (T(1) - a) * ei;
+  const T mid = a * (ew - ei) + ei;  // = a*ew + (1-a)*ei
   return t <= T(k::TI) ? ei : (t >= T(k::T0) ? ew : mid);
 }
 
 // es and slope of the mixed phase together (es_comp.py:177-200)
 template <class T>
 EKM_HD void es_slope_mixed(T t, T& es, T& des) {
-  T ew, dw, ei, di;
-  es_slope_water(t, ew, dw);
-  es_slope_ice(t, ei, di);
+  T ew = T(0), dw = T(0), ei = T(0), di = T(0);
+  if (EKM_ANY(!(t <= T(k::TI)))) es_slope_water(t, ew, dw);
+  if (EKM_ANY(!(t >= T(k::T0)))) es_slope_ice(t, ei, di);
   const T x = t - T(k::TI);
   const T a = m_sq(x * T(1.0 / (k::T0 - k::TI)));
   const T da = T(k::dalpha_c) * x;
-  const T mid = a * ew + (T(1) - a) * ei;
-  const T dmid = da * ew + a * dw - da * ei + (T(1) - a) * di;
+  const T dif = ew - ei;
+  const T mid = a * dif + ei;                   // a*ew + (1-a)*ei
+  const T dmid = da * dif + (a * (dw - di) + di);  // da*ew + a*dw - da*ei + (1-a)*di
   const bool ice = t <= T(k::TI), wat = t >= T(k::T0);
   es = ice ? ei : (wat ? ew : mid);
   des = ice ? di : (wat ? dw : dmid);
@@ -172,8 +196,8 @@ EKM_HD void es_slope_phase(T t, T& es, T& des) {  // es_comp.py:82-106
 
 template <class T>
 EKM_HD T t_from_es(T es) {  // es_comp.py:109-130 (always the water formula)
-  const T v = m_log(es * T(1.0 / k::C1));
-  return m_div(v * T(k::C4W) - T(k::C3W * k::T0), v - T(k::C3W));
+  const T l = m_log2(es * T(1.0 / k::C1));  // v = ln(es/C1) = l*ln2, folded into the constants
+  return m_div(l * T(k::LN2 * k::C4W) - T(k::C3W * k::T0), l * T(k::LN2) - T(k::C3W));
 }
 
 // ---- humidity conversions ---------------------------------------------------
@@ -358,6 +382,85 @@ EKM_HD T t_on_ma_bisect(T e, T p) {
   return t;
 }
 
+// Pressure-only terms of the moist-adiabat inversion.  With p a level vector they are
+// level constants; with p a field they cost one log2 and two exp2 per point.
+template <class T>
+struct PTerms {
+  T p;     // pressure (Pa)
+  T thf;   // (p0/p)^kappa   (thermo.py:829)
+  T pp;    // (p/p0)^kappa   (thermo.py:1109)
+  T dinv;  // 0.1859e-5*p + 0.6512 = 1/D(p)   (thermo.py:1100-1102)
+};
+
+template <class T>
+EKM_HD PTerms<T> pterms(T p) {
+  PTerms<T> r;
+  const T l = m_log2(p * T(1.0 / k::p0));
+  r.p = p;
+  r.thf = m_exp2(T(-k::kappa) * l);
+  r.pp = m_exp2(T(k::kappa) * l);
+  r.dinv = T(0.1859e-5) * p + T(0.6512);
+  return r;
+}
+
+// Davies-Jones inversion for the IFS theta_e (the path BASELINE.json configs 4/5 name):
+// same regimes, same single Newton step as thermo.py:1081-1159 + 1184-1197, with the
+// transcendental count cut to the minimum: powers as exp2 of one shared log2, c_te > D
+// tested as c_te*(1/D) > 1, 1/c_te as exp2 of the negated exponent, reciprocals shared
+// between qs and its slope, and regime / phase work skipped by whole waves that do not
+// need it.
+template <class T>
+EKM_HD T t_on_ma_newton_ifs(T e, const PTerms<T>& P) {
+  const T p = P.p, pp = P.pp;
+  const T lam = T(k::lambda);
+  const T te = e * pp;
+  const T lte = m_log2(te * T(1.0 / 273.16));
+  const T c_te = m_exp2(-lam * lte);  // (t0/te)^lambda
+  const T cd = c_te * P.dinv;         // c_te / D
+
+  // initial guess in deg C; later regimes overwrite earlier ones (thermo.py:1114-1128)
+  T tw = e;
+  if (EKM_ANY(cd > T(1))) {
+    T es, des;
+    es_slope_mixed(te, es, des);
+    T v = p - es;
+    if (v < T(k::eps_default)) v = nan_v<T>();
+    const T rv = m_rcp(v);
+    const T aw = T(2675 * k::eps) * es * rv;   // A*ws
+    T bw = T(2675 * k::eps) * des * rv;        // A*ws*des/es
+    if (!(es > T(0))) bw = nan_v<T>();         // the reference's 0*0/0 where es underflows
+    const T g1 = (te - T(273.16)) - aw * m_rcp(T(1) + bw);
+    if (cd > T(1)) tw = g1;
+  }
+  const T k1 = poly2(pp, -53.737, 137.81, -38.5);
+  const T k2 = poly2(pp, -0.384, 56.831, -4.392);
+  const T k2m = k2 - T(1.21);
+  if (T(1) <= c_te && cd <= T(1)) tw = k1 - k2 * c_te;
+  if (T(0.4) <= c_te && c_te < T(1)) tw = (k1 - T(1.21)) - k2m * c_te;
+  if (EKM_ANY(c_te < T(0.4))) {
+    const T g4 = (k1 - T(2.66)) - k2m * c_te + T(0.58) * m_exp2(lam * lte);  // 0.58/c_te
+    if (c_te < T(0.4)) tw = g4;
+  }
+  tw = tw + T(k::T0);
+
+  // one Newton step (thermo.py:1132-1149, 1184-1197)
+  const T rtw = m_rcp(tw);
+  const T c_tw = m_exp2(-lam * m_log2(tw * T(1.0 / 273.16)));
+  T es, des;
+  es_slope_mixed(tw, es, des);
+  T v = p + T(k::eps - 1) * es;
+  if ((p - es) < T(k::eps_default)) v = nan_v<T>();
+  const T rv = m_rcp(v);
+  const T qs = T(k::eps) * es * rv;
+  const T f = c_tw * m_exp2(T(-k::lambda * k::K0_ifs * k::LOG2E) * qs * rtw);
+  const T dqs = T(k::eps) * des * p * (rv * rv);
+  const T dg = T(k::K0_ifs) * rtw * (dqs - qs * rtw);
+  const T dlnf = -lam * (rtw + dg);
+  tw -= (f - c_te) * m_rcp(f * dlnf);
+  if (tw <= T(0)) tw = nan_v<T>();  // thermo.py:1155
+  return tw;
+}
+
 // Davies-Jones (2008): regime initial guess + exactly one Newton step
 // (max_iter = 1, thermo.py:1104), tw <= 0 -> NaN (thermo.py:1081-1159).
 template <int METHOD, class T>
@@ -426,6 +529,7 @@ EKM_HD T t_on_ma_newton(T e, T p) {
 template <int METHOD, int TM, class T>
 EKM_HD T t_on_ma(T e, T p) {  // thermo.py:1472-1509
   if (TM == T_BISECT) return t_on_ma_bisect<METHOD>(e, p);
+  if (METHOD == EPT_IFS) return t_on_ma_newton_ifs(e, pterms(p));
   return t_on_ma_newton<METHOD>(e, p);
 }
 

@@ -8,7 +8,7 @@ tests/_compare.py.  Everything here needs a real MI355X.
 import numpy as np
 import pytest
 
-from _compare import BISECT_QUANTUM, assert_parity, assert_same_nonfinite, bisect_unstable, rel_err
+from _compare import BISECT_QUANTUM, assert_parity, bisect_sign_noise, bisect_unstable, rel_err
 from _golden import case_inputs, case_outputs, golden, manifest
 from golden.known_answers import CASES as KAT
 
@@ -41,15 +41,20 @@ def _outs(x):
 def test_golden_vectors(ek, case):
     out = getattr(ek.thermo, case["func"])(*[a.copy() for a in case_inputs(case)], **case["kwargs"])
     bisect = case["kwargs"].get("t_method") == "bisect"
+    from oracle import thermo_oracle as orc_
+
+    cid = case["id"].split(".")
     for i, (o, g) in enumerate(zip(_outs(out), case_outputs(case))):
         want_dtype = np.float32 if case["dtype"] == "f32" else np.float64
         assert o.dtype == want_dtype, (case["id"], o.dtype)  # dtype-preserving (fp32 in -> fp32 out)
-        unstable = None
+        both = [golden()[".".join([cid[0], tag] + cid[2:]) + f".out{i}"] for tag in ("f32", "f64")]
+        unstable = ref64 = None
         if bisect:
-            cid = case["id"].split(".")
-            both = [golden()[".".join([cid[0], tag] + cid[2:]) + f".out{i}"] for tag in ("f32", "f64")]
-            unstable = bisect_unstable(*both)
-        assert_parity(o, g, case["dtype"], case["id"], bisect=bisect, unstable=unstable)
+            unstable = bisect_unstable(*both) | bisect_sign_noise(
+                orc_, case["func"], case_inputs(case), case["kwargs"], 3e-6 if case["dtype"] == "f32" else 1e-14)
+        elif case["dtype"] == "f32" and "newton" in case["id"]:
+            ref64 = both[1]  # the reference's own fp64 answer: conditioning yardstick for the Newton step
+        assert_parity(o, g, case["dtype"], case["id"], bisect=bisect, unstable=unstable, ref64=ref64)
 
 
 # ---- (2) the reference's inline known-answer vectors ----
@@ -163,7 +168,10 @@ def test_synthetic_bisect_vs_oracle(ek, orc, slab, tag, method):
     d64 = {k: v.astype(np.float64) for k, v in d32.items()} if tag == "f32" else d
     ref32 = orc.wet_bulb_temperature_from_specific_humidity(d32["t"], d32["q"], d32["p"], ept_method=method)
     ref64 = orc.wet_bulb_temperature_from_specific_humidity(d64["t"], d64["q"], d64["p"], ept_method=method)
-    unstable = bisect_unstable(ref32, ref64) if tag == "f32" else None
+    unstable = bisect_sign_noise(orc, "wet_bulb_temperature_from_specific_humidity", [d["t"], d["q"], d["p"]],
+                                 {"ept_method": method}, 3e-6 if tag == "f32" else 1e-14)
+    if tag == "f32":
+        unstable |= bisect_unstable(ref32, ref64)
     assert_parity(got, want, tag, f"bisect {method} {tag}", bisect=True, unstable=unstable)
     # the search lands on the same 120/4096 K lattice as the reference
     k = (got.astype(np.float64) - (273.16 - 20)) / BISECT_QUANTUM

@@ -183,8 +183,10 @@ EKM_API int ekm_event_sync(int dev, void* event);
 EKM_API int ekm_event_elapsed_ms(int dev, void* start, void* stop, float* ms);
 
 /* ---- launch tuning (process-wide; defaults are the measured best) ---- */
-EKM_API int ekm_set_tuning(int blocks_per_cu, int unroll);  /* 0 keeps a value */
-EKM_API int ekm_get_tuning(int* blocks_per_cu, int* unroll);
+/* tiles_per_block: consecutive 4-KiB tiles (256 lanes x 16 B) one workgroup streams per field;
+ * unroll: tiles in flight per lane per trip (1 or 2).  0 keeps a value. */
+EKM_API int ekm_set_tuning(int tiles_per_block, int unroll);
+EKM_API int ekm_get_tuning(int* tiles_per_block, int* unroll);
 
 /* ---- synthetic benchmark input, generated on the device (SURVEY.md 8d) ----
  * Fills t, q (and p unless NULL) for points [first, first+n) of a level-major

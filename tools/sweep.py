@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of kernel variants and launch tunings on one GPU, one process
-(cdna_hip_programming.md rule 24): for every (library variant, blocks_per_cu, unroll,
+(cdna_hip_programming.md rule 24): for every (library variant, tiles, unroll,
 workload) run R rounds of K launches, report median/min kernel ms and GB/s.
 
     python tools/sweep.py --libs default,variants/nont/libekm_thermo.so --workloads p3,full \
-        --bpc 4,8,16 --unroll 1,2 --rounds 5 --steps 5 --levels 137
+        --tiles 4,8,16 --unroll 1,2 --rounds 5 --steps 5 --levels 137
 """
 import argparse
 import ctypes as C
@@ -41,13 +41,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--libs", default="default")
     ap.add_argument("--workloads", default="p3,full")
-    ap.add_argument("--bpc", default="8")
+    ap.add_argument("--tiles", default="8")
     ap.add_argument("--unroll", default="1")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--levels", type=int, default=137)
     ap.add_argument("--pmode", default="field")
     ap.add_argument("--out", default="")
+    ap.add_argument("--skew", default="0", help="comma list: byte offset added to the k-th array's base (k*skew)")
     a = ap.parse_args()
 
     libs = {}
@@ -58,14 +59,18 @@ def main():
     chk = lambda rc: rc >= 0 or sys.exit(f"error {rc}: {base.ekm_last_error().decode()}")  # noqa: E731
     dev, n = 0, a.levels * INNER
 
+    skews = [int(x) for x in a.skew.split(",")]
+    maxskew = max(skews) * 10
+
     def dmalloc(nbytes):
         p = C.c_void_p()
-        chk(base.ekm_malloc(dev, nbytes, C.byref(p)))
+        chk(base.ekm_malloc(dev, nbytes + maxskew, C.byref(p)))
         return p.value
 
-    t, q, p = dmalloc(4 * n), dmalloc(4 * n), dmalloc(4 * n)
+    bases = [dmalloc(4 * n) for _ in range(9)]
     pl = dmalloc(4 * a.levels)
-    outs = [dmalloc(4 * n) for _ in range(6)]
+    t, q, p = bases[:3]
+    outs = bases[3:]
     chk(base.ekm_synth_fill_f32(dev, None, t, q, p, 0, n, INNER, a.levels, 20260313))
     chk(base.ekm_synth_levels_f32(dev, None, pl, a.levels))
     ev0, ev1 = C.c_void_p(), C.c_void_p()
@@ -75,17 +80,20 @@ def main():
     ops = {"t": F(t, 0, 0, 0, 0), "q": F(q, 0, 0, 0, 0),
            "p": F(p, 0, 0, 0, 0) if a.pmode == "field" else F(pl, 2, 0, a.levels, INNER)}
 
-    configs = [(ln, int(b), int(u), w) for ln in libs for b in a.bpc.split(",") for u in a.unroll.split(",")
-               for w in a.workloads.split(",")]
+    configs = [(ln, int(b), int(u), w, sk) for ln in libs for b in a.tiles.split(",") for u in a.unroll.split(",")
+               for w in a.workloads.split(",") for sk in skews]
     times = {c: [] for c in configs}
     for rnd in range(a.rounds + 1):  # round 0 = warm-up
         for c in configs:
-            ln, b, u, w = c
+            ln, b, u, w, sk = c
             lib = libs[ln]
             entry, which, ints, nout, bpp = W[w]
             chk(lib.ekm_set_tuning(b, u))
             fn = getattr(lib, f"ekm_{entry}_f32")
-            cargs = [dev, None] + [C.byref(ops[k]) for k in which] + list(ints) + outs[:nout] + [n]
+            sops = {"t": F(t, 0, 0, 0, 0), "q": F(q + sk, 0, 0, 0, 0),
+                    "p": F(p + 2 * sk, 0, 0, 0, 0) if a.pmode == "field" else ops["p"]}
+            cargs = [dev, None] + [C.byref(sops[k]) for k in which] + list(ints) + \
+                [o + (3 + i) * sk for i, o in enumerate(outs[:nout])] + [n]
             chk(fn(*cargs))
             chk(base.ekm_event_record(dev, ev0, None))
             for _ in range(a.steps):
@@ -98,12 +106,12 @@ def main():
                 times[c].append(ms.value / a.steps)
     rows = []
     for c in configs:
-        ln, b, u, w = c
+        ln, b, u, w, sk = c
         bpp = W[w][4] - (4 if a.pmode == "level" and "p" in W[w][1] else 0)
         med, mn = statistics.median(times[c]), min(times[c])
-        rows.append(dict(lib=ln, bpc=b, unroll=u, workload=w, med_ms=round(med, 4), min_ms=round(mn, 4),
+        rows.append(dict(lib=ln, tiles=b, unroll=u, workload=w, skew=sk, med_ms=round(med, 4), min_ms=round(mn, 4),
                          gbs_med=round(bpp * n / med / 1e6, 1), frac=round(bpp * n / med / 1e6 / 8000, 4)))
-        print(f"{ln:28s} bpc={b:<3d} u={u} {w:15s} med {med:8.4f} ms  min {mn:8.4f} ms  {rows[-1]['gbs_med']:8.1f} GB/s"
+        print(f"{ln:28s} tiles={b:<5d} u={u} skew={sk:<8d} {w:15s} med {med:8.4f} ms  min {mn:8.4f} ms  {rows[-1]['gbs_med']:8.1f} GB/s"
               f"  {rows[-1]['frac'] * 100:5.1f}%", flush=True)
     if a.out:
         with open(a.out, "w") as f:
