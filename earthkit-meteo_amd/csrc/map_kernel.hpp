@@ -263,6 +263,104 @@ __global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, 
   }
 }
 
+// ---- the usual broadcast shape: last operand (pressure) is a level vector or a scalar ----
+// Fields are streamed exactly as in map_fields; the level vector sits in LDS and a lane's
+// 16-B chunk almost always lies inside one level, so the pressure of the chunk is ONE
+// value: every sub-expression that depends on pressure alone (log2(p/p0), (p0/p)^kappa,
+// (p/p0)^kappa, 1/D(p), ...) is then computed once per chunk instead of once per point
+// (the compiler hoists it out of the unrolled per-point bodies), and p costs no HBM traffic.
+#ifndef EKM_LEVEL_LDS
+#define EKM_LEVEL_LDS 1
+#endif
+
+template <class Op, class T>
+__global__ __launch_bounds__(kThreads) void map_plast(const MapArgs<T, Op::NIN, Op::NOUT> a, unsigned tiles) {
+  constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N, PI = Op::NIN - 1;
+  typedef typename VecOf<T>::type Vec;
+  const bool lev = a.mode[PI] == EKM_LEVEL_MAJOR;
+  const unsigned long long inner = a.inner[PI];
+#if EKM_LEVEL_LDS
+  T* tab = reinterpret_cast<T*>(ekm_lds_raw);
+  if (lev) {
+    for (unsigned s = threadIdx.x; s < a.len[PI]; s += kThreads) tab[s] = a.in[PI][s];
+    __syncthreads();
+  }
+#else
+  const T* tab = a.in[PI];
+#endif
+  const T sval = lev ? T(0) : a.in[PI][0];
+  const unsigned last = lev ? a.len[PI] - 1 : 0;
+
+  const unsigned long long nvec = a.n / V;
+  const unsigned long long cblock = (unsigned long long)blockIdx.x * tiles * kThreads;  // wave-uniform
+  unsigned long long q = 0, r = 0;
+  if (lev) {  // one division per workgroup on the scalar unit, then carried forward per tile
+    const unsigned long long e = cblock * V;
+    q = e / inner;
+    r = e % inner + (unsigned long long)threadIdx.x * V;
+    while (r >= inner) {
+      r -= inner;
+      q += 1;
+    }
+  }
+
+  for (unsigned k = 0; k < tiles; ++k) {
+    const unsigned long long v = cblock + (unsigned long long)k * kThreads + threadIdx.x;
+    if (v < nvec) {
+      Vec xin[NIN], yout[NOUT];
+#pragma unroll
+      for (int i = 0; i < PI; ++i) xin[i] = ld_stream<T>(a.in[i] + v * V);
+      if (!lev || r + V <= inner) {  // the whole chunk has one pressure
+        const T pv = lev ? tab[q] : sval;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          T x[NIN], y[NOUT];
+#pragma unroll
+          for (int i = 0; i < PI; ++i) x[i] = xin[i][j];
+          x[PI] = pv;
+          Op::template apply<T>(x, y, a.rp);
+#pragma unroll
+          for (int o = 0; o < NOUT; ++o) yout[o][j] = y[o];
+        }
+      } else {  // the chunk straddles a level boundary (inner >= V: at most one)
+        const T pv0 = tab[q], pv1 = tab[q + 1 <= last ? q + 1 : last];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          T x[NIN], y[NOUT];
+#pragma unroll
+          for (int i = 0; i < PI; ++i) x[i] = xin[i][j];
+          x[PI] = (r + j < inner) ? pv0 : pv1;
+          Op::template apply<T>(x, y, a.rp);
+#pragma unroll
+          for (int o = 0; o < NOUT; ++o) yout[o][j] = y[o];
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) st_stream<T>(a.out[o] + v * V, yout[o]);
+    }
+    if (lev) {
+      q += a.step_q[PI];
+      r += a.step_r[PI];
+      if (r >= inner) {
+        r -= inner;
+        q += 1;
+      }
+    }
+  }
+  // ragged tail: n % V single elements, done by the first lanes of workgroup 0
+  const unsigned long long e = nvec * V + (unsigned long long)blockIdx.x * kThreads + threadIdx.x;
+  if (e < a.n) {
+    T x[NIN], y[NOUT];
+#pragma unroll
+    for (int i = 0; i < PI; ++i) x[i] = a.in[i][e];
+    unsigned long long l = lev ? e / inner : 0;
+    x[PI] = lev ? tab[l <= last ? l : last] : sval;
+    Op::template apply<T>(x, y, a.rp);
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) a.out[o][e] = y[o];
+  }
+}
+
 // ---- host side ----------------------------------------------------------------
 int set_error(int code, const char* fmt, ...);
 int device_cus(int dev);            // CU count of device `dev` (cached), <0 on error
@@ -346,7 +444,19 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
   const unsigned grid = (unsigned)((ntile + tiles - 1) / tiles);
   hipStream_t s = static_cast<hipStream_t>(stream);
 
-  if (!bc && aligned) {
+  bool plast = false;  // all fields aligned, only the last operand a level vector / scalar
+  if constexpr (NIN >= 2) {
+    plast = bc && aligned && (a.mode[NIN - 1] == EKM_LEVEL_MAJOR || a.mode[NIN - 1] == EKM_SCALAR);
+    for (int i = 0; i + 1 < NIN; ++i) plast = plast && a.mode[i] == EKM_FIELD;
+  }
+  if (plast) {
+    const unsigned long long step = (unsigned long long)kThreads * V;
+    if (a.mode[NIN - 1] == EKM_LEVEL_MAJOR) {
+      a.step_q[NIN - 1] = step / a.inner[NIN - 1];
+      a.step_r[NIN - 1] = step % a.inner[NIN - 1];
+    }
+    hipLaunchKernelGGL((map_plast<Op, T>), dim3(grid), dim3(kThreads), lds_elems * sizeof(T), s, a, tiles);
+  } else if (!bc && aligned) {
     if (unroll >= 2)
       hipLaunchKernelGGL((map_fields<Op, T, 2>), dim3(grid), dim3(kThreads), 0, s, a, tiles);
     else
