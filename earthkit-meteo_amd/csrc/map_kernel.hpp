@@ -27,6 +27,9 @@
 namespace ekm {
 
 constexpr int kThreads = 256;
+#ifndef EKM_WAVES_PER_EU
+#define EKM_WAVES_PER_EU 1
+#endif
 
 template <class T>
 struct VecOf;
@@ -90,7 +93,7 @@ __device__ __forceinline__ void st_stream(T* p, typename VecOf<T>::type v) {
 // moment the chip reads and writes one moving window of each stream.  Measured on
 // MI355X this beats a persistent grid-stride loop by 10-25 % (profiles/).
 template <class Op, class T, int UNROLL>
-__global__ __launch_bounds__(kThreads) void map_fields(const MapArgs<T, Op::NIN, Op::NOUT> a, unsigned tiles) {
+__global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_fields(const MapArgs<T, Op::NIN, Op::NOUT> a, unsigned tiles) {
   constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N;
   typedef typename VecOf<T>::type Vec;
   const unsigned long long nvec = a.n / V;
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, 
 #endif
 
 template <class Op, class T>
-__global__ __launch_bounds__(kThreads) void map_plast(const MapArgs<T, Op::NIN, Op::NOUT> a, unsigned tiles) {
+__global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_plast(const MapArgs<T, Op::NIN, Op::NOUT> a, unsigned tiles) {
   constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N, PI = Op::NIN - 1;
   typedef typename VecOf<T>::type Vec;
   const bool lev = a.mode[PI] == EKM_LEVEL_MAJOR;
