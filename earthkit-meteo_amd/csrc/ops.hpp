@@ -101,6 +101,24 @@ EKM_OP_T2(OpWetBulbFromTd, METHOD, TM, 3, 1,
           y[0] = (t_on_ma<METHOD, TM>(ept<METHOD, false>(x[0], x[1], x[2]), x[2]));)
 EKM_OP_T2(OpWetBulbFromQ, METHOD, TM, 3, 1,
           y[0] = (t_on_ma<METHOD, TM>(ept<METHOD, true>(x[0], x[1], x[2]), x[2]));)
+// The configuration BASELINE.json names (wet-bulb from q, IFS theta_e, Newton): the chain
+// thermo.py:1589-1590 with theta_e never formed -- te = theta_e*(p/p0)^kappa = t*exp(K0*q/t_lcl)
+// because the two pressure powers cancel, which drops one exp2 and the theta products.
+template <>
+struct OpWetBulbFromQ<EPT_IFS, T_NEWTON> {
+  static constexpr int NIN = 3;
+  static constexpr int NOUT = 1;
+  template <class T>
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T) {
+    const T t = x[0], q = x[1], p = x[2];
+    const T td = t_from_es(e_from_q(q, p));
+    const T tl = lcl_t<LCL_DAVIES>(t, td);
+    const T te = t * m_exp2(T(k::K0_ifs * k::LOG2E) * q * m_rcp(tl));
+    const T pp = m_exp2(T(k::kappa) * m_log2(p * T(1.0 / k::p0)));
+    y[0] = t_on_ma_newton_ifs_te(te, te, p, pp, T(0.1859e-5) * p + T(0.6512));
+  }
+};
+
 // thermo.py:1593-1675: "direct" closed form, else the moist adiabat followed to p0
 template <int METHOD, int TM, class T>
 EKM_HD T wbpt_from_ept(T e) {

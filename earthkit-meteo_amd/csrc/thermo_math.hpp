@@ -152,29 +152,38 @@ EKM_HD void es_slope_ice(T t, T& es, T& des) {
 // lane of the wave is above TI (below T0).
 template <class T>
 EKM_HD T es_mixed(T t) {
+  const bool ice = t <= T(k::TI), wat = t >= T(k::T0);
   T ew = T(0), ei = T(0);
-  if (EKM_ANY(!(t <= T(k::TI)))) ew = es_water(t);
-  if (EKM_ANY(!(t >= T(k::T0)))) ei = es_ice(t);
-  const T a = m_sq((t - T(k::TI)) * T(1.0 / (k::T0 - k::TI)));
-  const T mid = a * (ew - ei) + ei;  // = a*ew + (1-a)*ei
-  return t <= T(k::TI) ? ei : (t >= T(k::T0) ? ew : mid);
+  if (EKM_ANY(!ice)) ew = es_water(t);
+  if (EKM_ANY(!wat)) ei = es_ice(t);
+  T es = ice ? ei : ew;
+  if (EKM_ANY(!(ice || wat))) {  // some lane sits in the blend range (or is NaN)
+    const T a = m_sq((t - T(k::TI)) * T(1.0 / (k::T0 - k::TI)));
+    const T mid = a * (ew - ei) + ei;  // = a*ew + (1-a)*ei
+    es = (ice || wat) ? es : mid;
+  }
+  return es;
 }
 
 // es and slope of the mixed phase together (es_comp.py:177-200)
 template <class T>
 EKM_HD void es_slope_mixed(T t, T& es, T& des) {
-  T ew = T(0), dw = T(0), ei = T(0), di = T(0);
-  if (EKM_ANY(!(t <= T(k::TI)))) es_slope_water(t, ew, dw);
-  if (EKM_ANY(!(t >= T(k::T0)))) es_slope_ice(t, ei, di);
-  const T x = t - T(k::TI);
-  const T a = m_sq(x * T(1.0 / (k::T0 - k::TI)));
-  const T da = T(k::dalpha_c) * x;
-  const T dif = ew - ei;
-  const T mid = a * dif + ei;                   // a*ew + (1-a)*ei
-  const T dmid = da * dif + (a * (dw - di) + di);  // da*ew + a*dw - da*ei + (1-a)*di
   const bool ice = t <= T(k::TI), wat = t >= T(k::T0);
-  es = ice ? ei : (wat ? ew : mid);
-  des = ice ? di : (wat ? dw : dmid);
+  T ew = T(0), dw = T(0), ei = T(0), di = T(0);
+  if (EKM_ANY(!ice)) es_slope_water(t, ew, dw);
+  if (EKM_ANY(!wat)) es_slope_ice(t, ei, di);
+  es = ice ? ei : ew;
+  des = ice ? di : dw;
+  if (EKM_ANY(!(ice || wat))) {  // some lane sits in the blend range (or is NaN)
+    const T x = t - T(k::TI);
+    const T a = m_sq(x * T(1.0 / (k::T0 - k::TI)));
+    const T da = T(k::dalpha_c) * x;
+    const T dif = ew - ei;
+    const T mid = a * dif + ei;                      // a*ew + (1-a)*ei
+    const T dmid = da * dif + (a * (dw - di) + di);  // da*ew + a*dw - da*ei + (1-a)*di
+    es = (ice || wat) ? es : mid;
+    des = (ice || wat) ? des : dmid;
+  }
 }
 
 template <int PHASE, class T>
@@ -410,13 +419,20 @@ EKM_HD PTerms<T> pterms(T p) {
 // between qs and its slope, and regime / phase work skipped by whole waves that do not
 // need it.
 template <class T>
+EKM_HD T t_on_ma_newton_ifs_te(T e, T te, T p, T pp, T dinv);
+
+template <class T>
 EKM_HD T t_on_ma_newton_ifs(T e, const PTerms<T>& P) {
-  const T p = P.p, pp = P.pp;
+  return t_on_ma_newton_ifs_te(e, e * P.pp, P.p, P.pp, P.dinv);  // te = ept*(p/p0)^kappa, thermo.py:1110
+}
+
+// `e` is only the value the guess keeps when c_te is NaN (the result is NaN then anyway).
+template <class T>
+EKM_HD T t_on_ma_newton_ifs_te(T e, T te, T p, T pp, T dinv) {
   const T lam = T(k::lambda);
-  const T te = e * pp;
   const T lte = m_log2(te * T(1.0 / 273.16));
   const T c_te = m_exp2(-lam * lte);  // (t0/te)^lambda
-  const T cd = c_te * P.dinv;         // c_te / D
+  const T cd = c_te * dinv;           // c_te / D
 
   // initial guess in deg C; later regimes overwrite earlier ones (thermo.py:1114-1128)
   T tw = e;

@@ -60,35 +60,17 @@ def bisect_unstable(ref32, ref64):
 
 
 def bisect_sign_noise(orc, func, inputs, kwargs, thresh):
-    """Points whose bisection takes a rounding-determined decision: following the oracle's own
-    12-step path in fp64, some step's residual |ept*exp(-G) - th_sat| / th_sat is below `thresh`
-    (e.g. exactly saturated input, t == tw, where the residual at the second lattice point is
-    mathematically zero).  There `sign()` is noise in every implementation, the reference's
-    included, and one early flip can end in the p - es < eps NaN region."""
-    m = kwargs.get("ept_method", "ifs")
-    a = [np.asarray(x, dtype=np.float64) for x in inputs]
-    with np.errstate(all="ignore"):
-        if func == "temperature_on_moist_adiabat":
-            ept, p = a
-        else:
-            f = orc.ept_from_dewpoint if "dewpoint" in func else orc.ept_from_specific_humidity
-            ept = f(a[0], a[1], a[2], method=m)
-            p = a[2] if "potential" not in func else np.full_like(ept, orc.p0)
-        ept, p = np.broadcast_arrays(ept, p)
-        ept, p = ept.ravel().copy(), p.ravel().copy()
-        meth = orc._EPT[m]
-        t = np.full(ept.size, orc.T0 - 20.0)
-        dt = 120.0
-        noisy = np.zeros(ept.size, dtype=bool)
-        for _ in range(12):
-            st = orc._state(t=t, p=p)
-            dt /= 2.0
-            g = meth["gsat"](st, scale=-1.0)
-            th = meth["thsat"](st)
-            r = ept * np.exp(g) - th
-            noisy |= np.abs(r) <= thresh * np.abs(th)
-            t = t + np.sign(r) * dt
-    return noisy
+    """See oracle/conditioning.py (shared with bench.py)."""
+    from oracle import conditioning
+
+    return conditioning.bisect_sign_noise(func, inputs, kwargs, thresh)
+
+
+def newton_regime_boundary(func, inputs, kwargs, thresh):
+    """See oracle/conditioning.py: points whose Davies-Jones regime is decided by rounding."""
+    from oracle import conditioning
+
+    return conditioning.newton_regime_boundary(func, inputs, kwargs, thresh)
 
 
 def assert_parity(got, want, tag, what, bisect=False, rtol=None, unstable=None, ref64=None):
@@ -98,11 +80,14 @@ def assert_parity(got, want, tag, what, bisect=False, rtol=None, unstable=None, 
     evaluation cannot be expected closer than a few delta: the bar there is max(rtol, 4*delta), and
     at most 1e-4 of the points may need it."""
     rtol = RTOL[tag] if rtol is None else rtol
-    if bisect and unstable is not None and unstable.any():
-        assert unstable.sum() <= max(3, 0.10 * unstable.size), f"{what}: {unstable.sum()} reference-unstable points"
+    if unstable is not None and unstable.any():
+        lim = max(3, 0.10 * unstable.size) if bisect else max(3, 2e-4 * unstable.size)
+        assert unstable.sum() <= lim, f"{what}: {unstable.sum()} reference-unstable points"
         keep = ~np.asarray(unstable).ravel()
         got = np.asarray(got).ravel()[keep]
         want = np.asarray(want).ravel()[keep]
+        if ref64 is not None:
+            ref64 = np.asarray(ref64).ravel()[keep]
     assert_same_nonfinite(got, want, what)
     r = rel_err(got, want)
     if not bisect and ref64 is not None:

@@ -8,7 +8,7 @@ import pytest
 
 import _hosttwin
 from oracle import thermo_oracle as orc
-from _compare import assert_parity, bisect_sign_noise, bisect_unstable
+from _compare import assert_parity, bisect_sign_noise, bisect_unstable, newton_regime_boundary
 from _golden import case_inputs, case_outputs, golden, manifest
 
 CASES = manifest()
@@ -28,6 +28,9 @@ def test_kernel_math_vs_reference(case):
         if bisect:
             unstable = bisect_unstable(*both) | bisect_sign_noise(
                 orc, case["func"], case_inputs(case), case["kwargs"], 3e-6 if case["dtype"] == "f32" else 1e-14)
-        elif case["dtype"] == "f32" and "newton" in case["id"]:
-            ref64 = both[1]  # the reference's own fp64 answer: conditioning yardstick for the Newton step
+        elif "newton" in case["id"]:
+            unstable = newton_regime_boundary(case["func"], case_inputs(case), case["kwargs"],
+                                              1e-5 if case["dtype"] == "f32" else 1e-13)
+            if case["dtype"] == "f32":
+                ref64 = both[1]  # the reference's own fp64 answer: conditioning yardstick for the Newton step
         assert_parity(o, g, case["dtype"], case["id"], bisect=bisect, unstable=unstable, ref64=ref64)
