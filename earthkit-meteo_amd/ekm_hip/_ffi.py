@@ -66,6 +66,10 @@ def _signatures():
         "ekm_synth_fill_f64": ([i, vp, vp, vp, vp, u64, sz, u64, u32, u64], i),
         "ekm_synth_levels_f32": ([i, vp, vp, u32], i), "ekm_synth_levels_f64": ([i, vp, vp, u32], i),
     }
+    for tag, real in (("f32", C.c_float), ("f64", C.c_double)):
+        sig[f"ekm_pressure_on_hybrid_levels_{tag}"] = (
+            [i, vp, vp, vp, vp, sz, u32, vp, vp, i, real, vp, vp, vp, vp], i)
+        sig[f"ekm_any_le_{tag}"] = ([i, vp, vp, sz, real, real, real, vp], i)
     for name, (ins, outs, ints, has_eps) in OPS.items():
         for tag, real in (("f32", C.c_float), ("f64", C.c_double)):
             args = [i, vp] + [C.POINTER(Operand)] * len(ins) + [i] * len(ints)

@@ -1,0 +1,174 @@
+"""`earthkit.meteo.vertical.pressure_on_hybrid_levels` on MI355X -- the producer of the
+model-level pressure field the thermo kernels consume.
+
+Same signature, outputs, level selection/ordering and error messages as the reference
+(/root/reference/src/earthkit/meteo/vertical/array/vertical.py:505-740).  NumPy `sp` in ->
+NumPy out; `DeviceArray` `sp` in -> DeviceArrays out (then `vertical_axis` must be 0).
+`HybridPressure(A, B, sp)` hands the same definition to the thermo kernels instead of a
+materialised pressure field (ekm_hip.thermo functions accept it in place of `p`).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from .device import DeviceArray, _Allocation, current_device, current_stream
+
+_F32, _F64 = np.dtype(np.float32), np.dtype(np.float64)
+PRESSURE_TOA = 0.1  # vertical.py:674
+
+
+def _dev_bytes(host_array, device):
+    a = np.ascontiguousarray(host_array)
+    alloc = _Allocation(max(a.nbytes, 16), device)
+    lib = _ffi.lib()
+    _ffi.check(lib.ekm_h2d(device, alloc.ptr, a.ctypes.data, a.nbytes, current_stream()))
+    _ffi.check(lib.ekm_stream_sync(device, current_stream()))
+    return alloc
+
+
+def _compute_dtype(A, B, sp):
+    parts = [x.dtype for x in (A, B, sp)]
+    rd = np.result_type(*parts, 0.0)
+    return _F32 if rd == _F32 else _F64
+
+
+def _select_levels(A, B, levels):
+    """vertical.py:641-661: contiguous half-level range covering the request + row maps."""
+    nlev = A.shape[0] - 1
+    levels = np.asarray(levels)
+    lmax, lmin = int(levels.max()), int(levels.min())
+    if lmax > nlev:
+        raise ValueError(f"Requested level {lmax} exceeds the maximum number of levels {nlev}.")
+    if lmin < 1:
+        raise ValueError(f"Level numbering starts at 1. Found level={lmin} < 1.")
+    half_idx = np.arange(lmin - 1, lmax + 1)
+    out_half_idx = np.nonzero(levels[:, None] == half_idx[None, :])[1]  # local half index per requested level
+    return A[half_idx], B[half_idx], out_half_idx
+
+
+def pressure_on_hybrid_levels(A, B, sp, levels=None, alpha_top="ifs", output="full", vertical_axis=0):
+    """Pressure on hybrid full/half levels and the delta/alpha layer parameters (vertical.py:505-740)."""
+    if isinstance(output, str):
+        output = (output,)
+    if not output:
+        raise ValueError("At least one output type must be specified.")
+    for out in output:
+        if out not in ["full", "half", "alpha", "delta"]:
+            raise ValueError(f"Unknown output type '{out}'. Allowed values are 'full', 'half', 'alpha' or 'delta'.")
+    if alpha_top not in ["ifs", "arpege"]:
+        raise ValueError(f"Unknown method '{alpha_top}' for pressure calculation. Use 'ifs' or 'arpege'.")
+
+    A = np.asarray(A)
+    B = np.asarray(B)
+    on_device = isinstance(sp, DeviceArray)
+    if not on_device:
+        sp = np.asarray(sp)
+    if on_device and vertical_axis != 0 and sp.ndim > 0:
+        raise ValueError("DeviceArray input: outputs are level-major, vertical_axis must be 0")
+    dtype = _compute_dtype(A, B, sp)
+    device = sp.device if on_device else current_device()
+
+    sel = None
+    if levels is not None:
+        A, B, sel = _select_levels(A, B, levels)
+    nfull = A.shape[0] - 1
+    sp_shape = tuple(sp.shape)
+    npts = int(np.prod(sp_shape, dtype=np.int64))
+
+    # output rows: identity, or the requested levels in the requested order
+    if sel is None:
+        nrow_full, nrow_half, row_full, row_half = nfull, nfull + 1, None, None
+        dup = None
+    else:
+        uniq, first = np.unique(sel, return_index=True)
+        dup = None if len(uniq) == len(sel) else sel  # repeated levels: compute unique rows, then gather
+        order = uniq if dup is not None else sel
+        row_half = np.full(nfull + 1, -1, np.int32)
+        row_half[order] = np.arange(len(order), dtype=np.int32)
+        row_full = np.full(nfull, -1, np.int32)
+        row_full[order - 1] = np.arange(len(order), dtype=np.int32)
+        nrow_full = nrow_half = len(order)
+
+    lib = _ffi.lib()
+    stream = current_stream()
+    tag, real = ("f32", C.c_float) if dtype == _F32 else ("f64", C.c_double)
+    d_sp = sp if (on_device and sp.dtype == dtype) else DeviceArray.from_host(np.asarray(sp, dtype=dtype), device)
+    d_a = DeviceArray.from_host(A.astype(dtype), device)
+    d_b = DeviceArray.from_host(B.astype(dtype), device)
+    d_rf = _dev_bytes(row_full, device) if row_full is not None else None
+    d_rh = _dev_bytes(row_half, device) if row_half is not None else None
+
+    # the reference's global any(p_half[0] <= 0.1) (vertical.py:680, 694)
+    a0, b0 = float(A[0]), float(B[0])
+    if b0 == 0.0 or npts == 0:
+        top_is_zero = bool(a0 <= PRESSURE_TOA)
+    elif not on_device:
+        top_is_zero = bool(np.any(A[0].astype(dtype) + B[0].astype(dtype) * np.asarray(sp, dtype=dtype) <= PRESSURE_TOA))
+    else:
+        flag = _dev_bytes(np.zeros(1, np.int32), device)
+        _ffi.check(getattr(lib, f"ekm_any_le_{tag}")(device, stream, d_sp.ptr, npts, real(a0), real(b0),
+                                                     real(PRESSURE_TOA), flag.ptr))
+        host = np.zeros(1, np.int32)
+        _ffi.check(lib.ekm_d2h(device, host.ctypes.data, flag.ptr, 4, stream))
+        _ffi.check(lib.ekm_stream_sync(device, stream))
+        top_is_zero = bool(host[0])
+    a_top = float(np.log(2)) if alpha_top == "ifs" else 1.0
+
+    bufs = {}
+    for name in set(output):
+        rows = nrow_half if name == "half" else nrow_full
+        bufs[name] = DeviceArray.empty((rows,) + sp_shape, dtype, device)
+    ptr = lambda n: bufs[n].ptr if n in bufs else None  # noqa: E731
+    _ffi.check(getattr(lib, f"ekm_pressure_on_hybrid_levels_{tag}")(
+        device, stream, d_a.ptr, d_b.ptr, d_sp.ptr, npts, nfull, d_rf.ptr if d_rf else None,
+        d_rh.ptr if d_rh else None, int(top_is_zero), real(a_top), ptr("full"), ptr("half"), ptr("delta"),
+        ptr("alpha")))
+
+    res = []
+    if on_device:
+        _ffi.check(lib.ekm_stream_sync(device, stream))
+        for name in output:
+            arr = bufs[name]
+            if dup is not None:  # repeated levels: gather rows device-to-device
+                uniq = np.unique(dup)
+                out = DeviceArray.empty((len(dup),) + sp_shape, dtype, device)
+                row_bytes = npts * dtype.itemsize
+                for r, h in enumerate(dup):
+                    src = int(np.searchsorted(uniq, h))
+                    _ffi.check(lib.ekm_d2d(device, out.ptr + r * row_bytes, arr.ptr + src * row_bytes, row_bytes, stream))
+                _ffi.check(lib.ekm_stream_sync(device, stream))
+                arr = out
+            res.append(arr)
+    else:
+        for name in output:
+            h = bufs[name].to_host()
+            if dup is not None:
+                h = h[np.searchsorted(np.unique(dup), dup)]
+            if name in ("delta", "alpha") and h.dtype != _F64:
+                h = h.astype(np.float64)  # the reference allocates these with the default dtype (vertical.py:678, 687)
+            res.append(h)
+        for b in bufs.values():
+            b.free()
+        if vertical_axis != 0 and res[0].ndim > 1:
+            res = [np.moveaxis(r, 0, vertical_axis) for r in res]
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+class HybridPressure:
+    """Pressure on hybrid full levels given by its definition, p_k(x) = p_half[k] + 0.5*(p_half[k+1]-p_half[k])
+    with p_half[h] = A[h] + B[h]*sp(x), for use in place of a pressure field in ekm_hip.thermo calls on
+    `[level, ...sp.shape]` fields: the kernels form p from `sp` and the LDS-resident A/B tables, so the
+    pressure field is never read from (or written to) HBM."""
+
+    def __init__(self, A, B, sp):
+        self.A = np.ascontiguousarray(A, dtype=np.float64)
+        self.B = np.ascontiguousarray(B, dtype=np.float64)
+        if self.A.ndim != 1 or self.A.shape != self.B.shape or self.A.size < 2:
+            raise ValueError("A and B must be 1-D half-level tables of the same length >= 2")
+        self.sp = sp
+        self.nlev = self.A.size - 1
+
+    @property
+    def shape(self):
+        return (self.nlev,) + tuple(np.shape(self.sp))

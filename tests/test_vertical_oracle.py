@@ -1,0 +1,57 @@
+"""pressure_on_hybrid_levels: the oracle against vectors recorded from the reference (bit for bit)
+and against the data of the reference's own fixture (its tolerances)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import vertical_oracle as vo
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "vertical_golden.npz"))
+CASES = json.loads(bytes(G["manifest"]).decode())
+
+
+def case_args(c):
+    A, B = G[f"coef.{c['nlev']}.A"].copy(), G[f"coef.{c['nlev']}.B"].copy()
+    if c.get("top_offset"):
+        A = A + c["top_offset"]
+    dt = np.float32 if c["dtype"] == "f32" else np.float64
+    sp = G[f"sp.{c['sp']}"].astype(dt)
+    if c["dtype"] == "f32":
+        A, B = A.astype(dt), B.astype(dt)
+    return A, B, sp
+
+
+@pytest.mark.parametrize("c", CASES, ids=[c["id"] for c in CASES])
+def test_oracle_bit_exact(c):
+    A, B, sp = case_args(c)
+    res = vo.pressure_on_hybrid_levels(A, B, sp, levels=c["levels"], alpha_top=c["alpha_top"], output=c["output"],
+                                       vertical_axis=c["vertical_axis"])
+    res = res if isinstance(res, tuple) else (res,)
+    for name, r in zip(c["output"], res):
+        w = G[f"{c['id']}.{name}"]
+        assert r.dtype == w.dtype and np.array_equal(r, w, equal_nan=True), (c["id"], name)
+
+
+def test_oracle_vs_reference_fixture():
+    """tests/vertical/test_array_vertical.py:159-213 there: atol 1e-8 / rtol 1e-6 in fp64."""
+    A, B, sp = G["fixture.A"], G["fixture.B"], G["fixture.p_surf"]
+    full, half, delta, alpha = vo.pressure_on_hybrid_levels(A, B, sp, output=["full", "half", "delta", "alpha"])
+    for got, name in ((full, "p_full"), (half, "p_half"), (delta, "delta"), (alpha, "alpha")):
+        assert np.allclose(got, G[f"fixture.{name}"], atol=1e-8, rtol=1e-6), name
+
+
+def test_oracle_errors():
+    A, B, sp = G["coef.137.A"], G["coef.137.B"], np.array([1e5])
+    with pytest.raises(ValueError, match="Unknown output type"):
+        vo.pressure_on_hybrid_levels(A, B, sp, output="bogus")
+    with pytest.raises(ValueError, match="Unknown method"):
+        vo.pressure_on_hybrid_levels(A, B, sp, alpha_top="bogus")
+    with pytest.raises(ValueError, match="exceeds the maximum"):
+        vo.pressure_on_hybrid_levels(A, B, sp, levels=[138])
+    with pytest.raises(ValueError, match="starts at 1"):
+        vo.pressure_on_hybrid_levels(A, B, sp, levels=[0])
+    with pytest.raises(ValueError, match="At least one"):
+        vo.pressure_on_hybrid_levels(A, B, sp, output=[])

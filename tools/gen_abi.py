@@ -199,6 +199,27 @@ EKM_API int ekm_synth_fill_f64(int dev, void* stream, double* t, double* q, doub
 EKM_API int ekm_synth_levels_f32(int dev, void* stream, float* p_levels, uint32_t nlev);
 EKM_API int ekm_synth_levels_f64(int dev, void* stream, double* p_levels, uint32_t nlev);
 
+/* ---- hybrid model levels: the producer of the pressure field (SURVEY.md 8f rank 1) ----
+ * pressure_on_hybrid_levels: reference vertical/array/vertical.py:505-740.
+ * A, B: nfull+1 half-level coefficients of the (contiguous) level range, on the device;
+ * sp: npts surface pressures; outputs are [rows, npts] level-major, any may be NULL.
+ * row_full[k] / row_half[h] give the output row of layer k / half level h, or -1 to skip it
+ * (NULL = identity): this is how the reference's `levels=` selection and ordering is expressed.
+ * top_is_zero: the reference's any(p_half[0] <= 0.1) (see ekm_any_le_*); alpha_top: log(2) or 1. */
+EKM_API int ekm_pressure_on_hybrid_levels_f32(int dev, void* stream, const float* A, const float* B, const float* sp,
+                                              size_t npts, uint32_t nfull, const int32_t* row_full,
+                                              const int32_t* row_half, int top_is_zero, float alpha_top, float* full,
+                                              float* half, float* delta, float* alpha);
+EKM_API int ekm_pressure_on_hybrid_levels_f64(int dev, void* stream, const double* A, const double* B, const double* sp,
+                                              size_t npts, uint32_t nfull, const int32_t* row_full,
+                                              const int32_t* row_half, int top_is_zero, double alpha_top, double* full,
+                                              double* half, double* delta, double* alpha);
+/* *flag |= any(a0 + b0*sp[i] <= thresh); *flag must be zeroed by the caller (ekm_memset) */
+EKM_API int ekm_any_le_f32(int dev, void* stream, const float* sp, size_t n, float a0, float b0, float thresh,
+                           int32_t* flag);
+EKM_API int ekm_any_le_f64(int dev, void* stream, const double* sp, size_t n, double a0, double b0, double thresh,
+                           int32_t* flag);
+
 /* ---- thermo entry points ----
  * Argument order: dev, stream, inputs..., enum parameters..., [eps], outputs..., n. */
 '''
