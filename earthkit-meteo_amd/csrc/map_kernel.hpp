@@ -58,6 +58,8 @@ struct MapArgs {
   unsigned long long step_q[NIN];  // (elements per tile) / inner   resp. unused
   unsigned long long step_r[NIN];  // (elements per tile) % inner   resp. % len
   int vec_ok;                    // all field pointers 16-B aligned
+  const T* aux0;                 // EKM_HYBRID_FULL (last operand): A half-level table
+  const T* aux1;                 //                                 B half-level table
 };
 
 #ifndef EKM_NT_LOAD
@@ -277,27 +279,44 @@ __global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, 
 #endif
 
 template <class Op, class T>
-__global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_plast(const MapArgs<T, Op::NIN, Op::NOUT> a, unsigned tiles) {
+__global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_plast(const MapArgs<T, Op::NIN, Op::NOUT> a,
+                                                                      unsigned tiles) {
   constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N, PI = Op::NIN - 1;
   typedef typename VecOf<T>::type Vec;
-  const bool lev = a.mode[PI] == EKM_LEVEL_MAJOR;
+  const int mode = a.mode[PI];
+  const bool lev = mode == EKM_LEVEL_MAJOR, hyb = mode == EKM_HYBRID_FULL;
   const unsigned long long inner = a.inner[PI];
+  T* lds = reinterpret_cast<T*>(ekm_lds_raw);
 #if EKM_LEVEL_LDS
-  T* tab = reinterpret_cast<T*>(ekm_lds_raw);
+  const T* tab = lds;
   if (lev) {
-    for (unsigned s = threadIdx.x; s < a.len[PI]; s += kThreads) tab[s] = a.in[PI][s];
+    for (unsigned s = threadIdx.x; s < a.len[PI]; s += kThreads) lds[s] = a.in[PI][s];
     __syncthreads();
   }
 #else
   const T* tab = a.in[PI];
 #endif
-  const T sval = lev ? T(0) : a.in[PI][0];
-  const unsigned last = lev ? a.len[PI] - 1 : 0;
+  const unsigned nhalf = a.len[PI] + 1;
+  if (hyb) {  // A then B half-level tables in LDS
+    for (unsigned s = threadIdx.x; s < nhalf; s += kThreads) {
+      lds[s] = a.aux0[s];
+      lds[nhalf + s] = a.aux1[s];
+    }
+    __syncthreads();
+  }
+  const T sval = (lev || hyb) ? T(0) : a.in[PI][0];
+  const unsigned last = (lev || hyb) ? a.len[PI] - 1 : 0;
+  // pressure of full level l at surface pressure s (vertical.py:670, 708)
+  auto hybrid_p = [&](unsigned long long l, T s) {
+    const T ph0 = lds[l] + lds[nhalf + l] * s;
+    const T ph1 = lds[l + 1] + lds[nhalf + l + 1] * s;
+    return ph0 + T(0.5) * (ph1 - ph0);
+  };
 
   const unsigned long long nvec = a.n / V;
   const unsigned long long cblock = (unsigned long long)blockIdx.x * tiles * kThreads;  // wave-uniform
   unsigned long long q = 0, r = 0;
-  if (lev) {  // one division per workgroup on the scalar unit, then carried forward per tile
+  if (lev || hyb) {  // one division per workgroup on the scalar unit, then carried forward per tile
     const unsigned long long e = cblock * V;
     q = e / inner;
     r = e % inner + (unsigned long long)threadIdx.x * V;
@@ -313,7 +332,33 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_plast(const Ma
       Vec xin[NIN], yout[NOUT];
 #pragma unroll
       for (int i = 0; i < PI; ++i) xin[i] = ld_stream<T>(a.in[i] + v * V);
-      if (!lev || r + V <= inner) {  // the whole chunk has one pressure
+      if (hyb) {
+        const T* sp = a.in[PI];
+        if (r + V <= inner && (r % V) == 0 && a.vec_ok) {  // aligned chunk inside one level
+          const Vec s = *reinterpret_cast<const Vec*>(sp + r);  // cached load: sp is re-read per level
+#pragma unroll
+          for (int j = 0; j < V; ++j) xin[PI][j] = hybrid_p(q, s[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            unsigned long long l = q, rr = r + j;
+            if (rr >= inner) {
+              rr -= inner;
+              l = l + 1 <= last ? l + 1 : last;
+            }
+            xin[PI][j] = hybrid_p(l, sp[rr]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          T x[NIN], y[NOUT];
+#pragma unroll
+          for (int i = 0; i < NIN; ++i) x[i] = xin[i][j];
+          Op::template apply<T>(x, y, a.rp);
+#pragma unroll
+          for (int o = 0; o < NOUT; ++o) yout[o][j] = y[o];
+        }
+      } else if (!lev || r + V <= inner) {  // the whole chunk has one pressure
         const T pv = lev ? tab[q] : sval;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
@@ -341,7 +386,7 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_plast(const Ma
 #pragma unroll
       for (int o = 0; o < NOUT; ++o) st_stream<T>(a.out[o] + v * V, yout[o]);
     }
-    if (lev) {
+    if (lev || hyb) {
       q += a.step_q[PI];
       r += a.step_r[PI];
       if (r >= inner) {
@@ -356,8 +401,9 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_plast(const Ma
     T x[NIN], y[NOUT];
 #pragma unroll
     for (int i = 0; i < PI; ++i) x[i] = a.in[i][e];
-    unsigned long long l = lev ? e / inner : 0;
-    x[PI] = lev ? tab[l <= last ? l : last] : sval;
+    unsigned long long l = (lev || hyb) ? e / inner : 0;
+    if (l > last) l = last;
+    x[PI] = hyb ? hybrid_p(l, a.in[PI][e % inner]) : (lev ? tab[l] : sval);
     Op::template apply<T>(x, y, a.rp);
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) a.out[o][e] = y[o];
@@ -380,6 +426,7 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
   int rc = use_device(dev);
   if (rc != EKM_OK) return rc;
   MapArgs<T, NIN, NOUT> a;
+  a.aux0 = a.aux1 = nullptr;
   a.n = n;
   a.rp = T(rp);
   bool bc = false, aligned = true;
@@ -423,6 +470,22 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
         }
         break;
       }
+      case EKM_HYBRID_FULL: {
+        bc = true;
+        if (i != NIN - 1 || NIN < 2)
+          return set_error(EKM_ERR_ARG, "operand %d: EKM_HYBRID_FULL is supported for the last operand only", i);
+        if (!op->aux0 || !op->aux1) return set_error(EKM_ERR_ARG, "operand %d: EKM_HYBRID_FULL needs the A and B tables", i);
+        if (op->len == 0 || op->len > 8000u || op->inner < (unsigned)V || (unsigned long long)op->len * op->inner < n)
+          return set_error(EKM_ERR_ARG, "operand %d: EKM_HYBRID_FULL needs 0 < len <= 8000, inner >= %d, len*inner >= n", i,
+                           V);
+        if (reinterpret_cast<uintptr_t>(op->data) % 16) aligned = false;
+        a.len[i] = (unsigned)op->len;
+        a.inner[i] = op->inner;
+        a.aux0 = static_cast<const T*>(op->aux0);
+        a.aux1 = static_cast<const T*>(op->aux1);
+        lds_elems += 2 * ((a.len[i] + 1 + 3u) & ~3u);
+        break;
+      }
       default:
         return set_error(EKM_ERR_ARG, "operand %d: unknown mode %d", i, op->mode);
     }
@@ -449,16 +512,19 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
 
   bool plast = false;  // all fields aligned, only the last operand a level vector / scalar
   if constexpr (NIN >= 2) {
-    plast = bc && aligned && (a.mode[NIN - 1] == EKM_LEVEL_MAJOR || a.mode[NIN - 1] == EKM_SCALAR);
+    plast = bc && aligned && (a.mode[NIN - 1] == EKM_LEVEL_MAJOR || a.mode[NIN - 1] == EKM_SCALAR ||
+                              a.mode[NIN - 1] == EKM_HYBRID_FULL);
     for (int i = 0; i + 1 < NIN; ++i) plast = plast && a.mode[i] == EKM_FIELD;
   }
   if (plast) {
     const unsigned long long step = (unsigned long long)kThreads * V;
-    if (a.mode[NIN - 1] == EKM_LEVEL_MAJOR) {
+    if (a.mode[NIN - 1] == EKM_LEVEL_MAJOR || a.mode[NIN - 1] == EKM_HYBRID_FULL) {
       a.step_q[NIN - 1] = step / a.inner[NIN - 1];
       a.step_r[NIN - 1] = step % a.inner[NIN - 1];
     }
     hipLaunchKernelGGL((map_plast<Op, T>), dim3(grid), dim3(kThreads), lds_elems * sizeof(T), s, a, tiles);
+  } else if (a.aux0) {
+    return set_error(EKM_ERR_ARG, "EKM_HYBRID_FULL needs 16-B aligned full-field operands before it");
   } else if (!bc && aligned) {
     if (unroll >= 2)
       hipLaunchKernelGGL((map_fields<Op, T, 2>), dim3(grid), dim3(kThreads), 0, s, a, tiles);

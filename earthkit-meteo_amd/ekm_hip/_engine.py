@@ -18,6 +18,7 @@ import numpy as np
 from . import _ffi
 from ._optable import OPS
 from .device import DeviceArray, current_device, current_stream
+from .vertical import HybridPressure
 
 _F32, _F64 = np.dtype(np.float32), np.dtype(np.float64)
 _MAX_LDS_BYTES = 64 * 1024
@@ -28,6 +29,8 @@ def _result_dtype(args):
     """NumPy promotion with weak Python scalars; anything non-float computes in float64."""
     parts = []
     for a in args:
+        if isinstance(a, HybridPressure):
+            a = a.sp
         if isinstance(a, DeviceArray):
             parts.append(a.dtype)
         elif isinstance(a, (bool, int, float)):
@@ -81,6 +84,10 @@ class _Plan:
     """Normalised operands of one call."""
 
     def __init__(self, args, dtype_override=None):
+        self.hybrid = [a for a in args if isinstance(a, HybridPressure)]
+        if self.hybrid and args[-1] is not self.hybrid[0] or len(self.hybrid) > 1:
+            raise ValueError("HybridPressure can only stand in for the last (pressure) argument")
+        args = [a.sp if isinstance(a, HybridPressure) else a for a in args]
         self.on_device = any(isinstance(a, DeviceArray) for a in args)
         self.out_dtype, self.dtype = _result_dtype(args)
         if dtype_override is not None:
@@ -100,7 +107,11 @@ class _Plan:
                 h = np.asarray(a)
                 self.host.append(h)
                 shapes.append(h.shape)
+        if self.hybrid:  # p has the shape [level, ...sp.shape]; the fields must have exactly that shape
+            shapes[-1] = self.hybrid[0].shape
         self.shape = tuple(np.broadcast_shapes(*shapes))
+        if self.hybrid and (self.shape != self.hybrid[0].shape or any(tuple(s) != self.shape for s in shapes[:-1])):
+            raise ValueError(f"HybridPressure of shape {self.hybrid[0].shape} needs fields of exactly that shape")
         self.n = int(np.prod(self.shape, dtype=np.int64))
 
 
@@ -117,7 +128,16 @@ def run(name, args, ints=(), eps=None, dtype=None):
     temps = []  # device buffers owned by this call
     operands = []
     lds_bytes = 0
-    for a in plan.host:
+    for k, a in enumerate(plan.host):
+        if plan.hybrid and k == len(plan.host) - 1:
+            hp = plan.hybrid[0]
+            sp = a if isinstance(a, DeviceArray) and a.dtype == plan.dtype else DeviceArray.from_host(
+                np.ascontiguousarray(np.asarray(a), dtype=plan.dtype), device=dev)
+            tabs = [DeviceArray.from_host(x.astype(plan.dtype), device=dev) for x in (hp.A, hp.B)]
+            temps.extend(tabs + ([sp] if sp is not a else []))
+            inner = max(1, sp.size)
+            operands.append(_ffi.Operand(sp.ptr, _ffi.HYBRID_FULL, 0, hp.nlev, inner, tabs[0].ptr, tabs[1].ptr))
+            continue
         shape = a.shape
         cls = classify(shape, plan.shape) if plan.n else (_ffi.FIELD, 0, 0)
         if cls is not None and cls[0] >= _ffi.LEVEL_MAJOR:

@@ -12,7 +12,7 @@ from ._optable import OPS
 
 EKM_OK = 0
 EKM_ERR_HIP, EKM_ERR_ARG, EKM_ERR_ENUM, EKM_ERR_NODEV = -1, -2, -3, -4
-FIELD, SCALAR, LEVEL_MAJOR, LEVEL_MINOR = 0, 1, 2, 3
+FIELD, SCALAR, LEVEL_MAJOR, LEVEL_MINOR, HYBRID_FULL = 0, 1, 2, 3, 4
 
 PHASE = {"mixed": 0, "water": 1, "ice": 2}
 EPT_METHOD = {"ifs": 0, "bolton35": 1, "bolton39": 2}
@@ -30,7 +30,7 @@ class EkmLibraryError(ImportError):
 
 class Operand(C.Structure):
     _fields_ = [("data", C.c_void_p), ("mode", C.c_int32), ("reserved", C.c_int32),
-                ("len", C.c_uint64), ("inner", C.c_uint64)]
+                ("len", C.c_uint64), ("inner", C.c_uint64), ("aux0", C.c_void_p), ("aux1", C.c_void_p)]
 
 
 _lib = None

@@ -70,3 +70,42 @@ def test_device_resident_and_errors(ek):
         ek.vertical.pressure_on_hybrid_levels(A, B, sp, levels=[138])
     with pytest.raises(ValueError, match="starts at 1"):
         ek.vertical.pressure_on_hybrid_levels(A, B, sp, levels=[0])
+
+
+@pytest.mark.parametrize("tag,dt", [("f32", np.float32), ("f64", np.float64)])
+def test_hybrid_pressure_operand(ek, tag, dt):
+    """Thermo kernels fed the DEFINITION of the model-level pressure (A, B, sp) instead of a pressure
+    field: same results as with the materialised field from pressure_on_hybrid_levels."""
+    from _compare import assert_parity
+    from oracle import synthetic, thermo_oracle as orc, vertical_oracle as vo
+
+    # the lowest 101 layers (p > ~25 hPa): above that the synthetic humidity is unphysical and the
+    # reference's own fp32 and fp64 wet-bulb disagree at the 1e-2 level (SURVEY.md B.5)
+    A, B = G["coef.137.A"][36:], G["coef.137.B"][36:]
+    rng = np.random.default_rng(11)
+    for npts in (1031, 4096):  # odd: chunks straddle level boundaries; multiple of 4: the aligned path
+        sp = rng.uniform(5.2e4, 1.04e5, npts).astype(dt)
+        pfull = vo.pressure_on_hybrid_levels(A.astype(dt), B.astype(dt), sp)
+        t = (synthetic.standard_temperature(pfull) + rng.normal(0, 8, pfull.shape)).astype(dt)
+        q = np.minimum(orc.specific_humidity_from_relative_humidity(t.astype(np.float64), rng.uniform(1, 100, t.shape),
+                                                                    pfull.astype(np.float64)), 0.04).astype(dt)
+        hp = ek.HybridPressure(A, B, sp)
+        for func, args in (("potential_temperature", (t,)), ("relative_humidity_from_specific_humidity", (t, q)),
+                           ("pipeline_svp_td_rh", (t, q)), ("pipeline_full", (t, q))):
+            got = getattr(ek.thermo, func)(*args, hp)
+            want = getattr(orc, func)(*[a.copy() for a in args], pfull.copy())
+            got = got if isinstance(got, tuple) else (got,)
+            want = want if isinstance(want, tuple) else (want,)
+            from oracle import conditioning
+            edge = conditioning.newton_regime_boundary("pipeline_full", [t, q, pfull], {}, 1e-5 if tag == "f32" else 1e-13)
+            for k, (g_, w_) in enumerate(zip(got, want)):
+                assert g_.shape == pfull.shape and g_.dtype == dt
+                assert_parity(g_, w_, tag, f"{func} hybrid p {tag} npts={npts}",
+                              unstable=edge if (func == "pipeline_full" and k == 5) else None)
+    # device-resident sp and fields
+    dsp, dtt = ek.to_device(sp), ek.to_device(t)
+    th = ek.thermo.potential_temperature(dtt, ek.HybridPressure(A, B, dsp))
+    assert isinstance(th, ek.DeviceArray)
+    assert_parity(th.to_host(), orc.potential_temperature(t, pfull), tag, "device-resident hybrid p")
+    with pytest.raises(ValueError):
+        ek.thermo.potential_temperature(t[:5], hp)

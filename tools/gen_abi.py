@@ -145,13 +145,20 @@ extern "C" {
 #define EKM_SCALAR 1       /* data[0] for every point                                 */
 #define EKM_LEVEL_MAJOR 2  /* data[i / inner]: `len` levels of `inner` points each    */
 #define EKM_LEVEL_MINOR 3  /* data[i % len]: the vector runs along the fastest axis   */
+#define EKM_HYBRID_FULL 4  /* pressure on hybrid full levels formed in the kernel:
+                              data = surface pressure sp (`inner` values), `len` full levels,
+                              aux0/aux1 = A/B half-level tables (len+1 values each);
+                              value = ph(k) + 0.5*(ph(k+1)-ph(k)), ph(h) = A[h] + B[h]*sp[i % inner],
+                              k = i / inner  (vertical/array/vertical.py:670,708).  Last operand only. */
 
 typedef struct ekm_operand {
   const void* data; /* device pointer (float* for _f32, double* for _f64)         */
   int32_t mode;     /* EKM_FIELD / EKM_SCALAR / EKM_LEVEL_MAJOR / EKM_LEVEL_MINOR */
   int32_t reserved; /* 0                                                           */
   uint64_t len;     /* vector length for the LEVEL modes, else ignored            */
-  uint64_t inner;   /* points per level for EKM_LEVEL_MAJOR, else ignored         */
+  uint64_t inner;   /* points per level for EKM_LEVEL_MAJOR / EKM_HYBRID_FULL      */
+  const void* aux0; /* EKM_HYBRID_FULL: A table (device), else NULL                */
+  const void* aux1; /* EKM_HYBRID_FULL: B table (device), else NULL                */
 } ekm_operand;
 
 /* ---- lifecycle ---- */
