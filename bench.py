@@ -46,6 +46,8 @@ WORKLOADS = {
     "theta": ("potential_temperature", 2, 1, 12, "potential temperature"),
     "svp": ("saturation_vapour_pressure", 1, 1, 8, "saturation vapour pressure (mixed)"),
     "ept": ("ept_from_specific_humidity", 3, 1, 16, "theta_e (ifs)"),
+    # the producer of p; reads sp once (1/137 of 4 B/pt), writes p_full
+    "hybrid_levels": ("pressure_on_hybrid_levels", 0, 1, 4, "p_full on hybrid levels from sp (A, B tables)"),
 }
 
 
@@ -55,8 +57,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="full", choices=sorted(WORKLOADS))
-    ap.add_argument("--pmode", default="field", choices=["field", "level"],
-                    help="pressure as a full field, or as the 137-level vector staged in LDS")
+    ap.add_argument("--pmode", default="field", choices=["field", "level", "hybrid"],
+                    help="pressure as a full field, as the 137-level vector staged in LDS, or formed in the kernel "
+                         "from surface pressure and the IFS L137 A/B tables (hybrid model levels)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: one full global field per GPU; strong: one global field split across GPUs")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
@@ -148,6 +151,7 @@ class Dist:
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # single node: never depend on hostname resolution
             td.init_process_group("gloo", rank=self.rank, world_size=self.world,
                                   timeout=datetime.timedelta(seconds=600))
             self.td = td
@@ -184,8 +188,8 @@ def main():
     itemsize = 4 if args.dtype == "f32" else 8
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
     bpp = bpp * itemsize // 4
-    if args.pmode == "level" and nin >= 2:
-        bpp -= itemsize  # p is not read per point
+    if args.pmode in ("level", "hybrid") and nin >= 2:
+        bpp -= itemsize  # p is not read per point (hybrid: sp is 1/137 of a field and served from cache)
     nlev = args.levels
     n_field = nlev * INNER
     if args.scaling == "weak":
@@ -221,11 +225,32 @@ def main():
         t = DeviceArray.empty(shape, np_dtype, dev)
         q = DeviceArray.empty(shape, np_dtype, dev)
         p = DeviceArray.empty(shape, np_dtype, dev) if args.pmode == "field" else None
-        fill = getattr(lib, f"ekm_synth_fill_{args.dtype}")
         seed = 20260313 + (dist.rank if args.scaling == "weak" else 0)
-        _ffi.check(fill(dev, None, t.ptr, q.ptr, p.ptr if p else None, first, n_local, INNER, nlev, seed))
         plev = DeviceArray.empty((nlev,), np_dtype, dev)
         _ffi.check(getattr(lib, f"ekm_synth_levels_{args.dtype}")(dev, None, plev.ptr, nlev))
+        hyb = None
+        if args.pmode == "hybrid" or args.workload == "hybrid_levels":
+            # IFS L137 half-level tables (data recorded from the reference's conf/ifs_levels_conf.json)
+            assert first == 0 and nlev <= 137, "hybrid mode: whole fields only"
+            g = np.load(os.path.join(ROOT, "tests", "golden", "vertical_golden.npz"))
+            A, B = g["coef.137.A"][137 - nlev:], g["coef.137.B"][137 - nlev:]
+            rng = np.random.default_rng(seed)
+            sp_host = (101325.0 * (1.0 - 0.35 * rng.random(INNER) ** 3)).astype(np_dtype)  # mostly near sea level, some orography
+            hyb = dict(A=DeviceArray.from_host(A.astype(np_dtype), dev), B=DeviceArray.from_host(B.astype(np_dtype), dev),
+                       sp=DeviceArray.from_host(sp_host, dev), Ah=A, Bh=B, sph=sp_host)
+        if args.pmode == "hybrid":
+            # t, q drawn around the hybrid-level pressure (materialised once, then dropped)
+            ptmp = DeviceArray.empty(shape, np_dtype, dev)
+            _ffi.check(getattr(lib, f"ekm_pressure_on_hybrid_levels_{args.dtype}")(
+                dev, None, hyb["A"].ptr, hyb["B"].ptr, hyb["sp"].ptr, INNER, nlev, None, None, 1,
+                float(np.log(2)), ptmp.ptr, None, None, None))
+            _ffi.check(getattr(lib, f"ekm_synth_fill_given_p_{args.dtype}")(dev, None, t.ptr, q.ptr, ptmp.ptr, first,
+                                                                             n_local, seed))
+            _ffi.check(lib.ekm_sync(dev))
+            ptmp.free()
+        else:
+            fill = getattr(lib, f"ekm_synth_fill_{args.dtype}")
+            _ffi.check(fill(dev, None, t.ptr, q.ptr, p.ptr if p else None, first, n_local, INNER, nlev, seed))
         outs = [DeviceArray.empty(shape, np_dtype, dev) for _ in range(nout)]
 
         fn = getattr(lib, f"ekm_{entry}_{args.dtype}")
@@ -233,6 +258,8 @@ def main():
         op_t, op_q = F(t.ptr, _ffi.FIELD, 0, 0, 0), F(q.ptr, _ffi.FIELD, 0, 0, 0)
         if p is not None:
             op_p = F(p.ptr, _ffi.FIELD, 0, 0, 0)
+        elif args.pmode == "hybrid":
+            op_p = F(hyb["sp"].ptr, _ffi.HYBRID_FULL, 0, nlev, INNER, hyb["A"].ptr, hyb["B"].ptr)
         else:  # level vector: index = (first + i) // INNER; shards start on a level boundary only at rank 0,
             # so a shard passes the sub-vector starting at its first level and an offset-free inner
             assert first % INNER == 0 or args.scaling == "weak", "level mode needs level-aligned shards"
@@ -242,9 +269,13 @@ def main():
                     "wet_bulb_temperature_from_specific_humidity": (op_t, op_q, op_p),
                     "relative_humidity_from_specific_humidity": (op_t, op_q, op_p),
                     "ept_from_specific_humidity": (op_t, op_q, op_p),
-                    "potential_temperature": (op_t, op_p), "saturation_vapour_pressure": (op_t,)}[entry]
+                    "potential_temperature": (op_t, op_p), "saturation_vapour_pressure": (op_t,),
+                    "pressure_on_hybrid_levels": ()}[entry]
         ints = {"wetbulb": (0, 1), "wetbulb_bisect": (0, 0), "svp": (0,), "ept": (0,)}.get(args.workload, ())
         cargs = [dev, None] + [C.byref(o) for o in operands] + list(ints) + [o.ptr for o in outs] + [n_local]
+        if args.workload == "hybrid_levels":
+            cargs = [dev, None, hyb["A"].ptr, hyb["B"].ptr, hyb["sp"].ptr, INNER, nlev, None, None, 1,
+                     float(np.log(2)), outs[0].ptr, None, None, None]
 
         def step():
             _ffi.check(fn(*cargs))
@@ -279,7 +310,7 @@ def main():
         _ffi.check(lib.ekm_event_elapsed_ms(dev, ev0, ev1, C.byref(ms)))
         kernel_ms = dist.reduce(ms.value / args.steps, "max")  # average launch duration, slowest rank
         if dist.rank == 0:
-            parity = check_parity(args, t, q, p, plev, outs, n_local, first, nlev, np_dtype)
+            parity = check_parity(args, t, q, p, plev, outs, n_local, first, nlev, np_dtype, hyb)
 
     if dist.rank == 0:
         value = None if args.dry_run else n_total * args.steps / elapsed
@@ -287,7 +318,7 @@ def main():
         if kernel_ms:
             achieved = bpp * n_local / (kernel_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles(args),
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles(args, n_local),
                     "kernel": entry, "bytes_per_point": bpp, "points_per_launch": n_local,
                     "kernel_ms": round(kernel_ms, 4)}
         line = {
@@ -298,7 +329,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{desc} on {nlev}x{NLAT}x{NLON} {args.dtype} "
                                    f"({'one field per GPU' if args.scaling == 'weak' else 'one field split by grid point'}),"
-                                   f" p as {'full field' if args.pmode == 'field' else '137-level vector in LDS'}",
+                                   f" p as {dict(field='full field', level='137-level vector in LDS', hybrid='hybrid levels formed in-kernel from sp + A/B tables')[args.pmode]}",
                        "entry_point": f"ekm_{entry}_{args.dtype}", "points_per_gpu": n_local, "p_mode": args.pmode},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
@@ -308,11 +339,14 @@ def main():
     dist.close()
 
 
-def check_parity(args, t, q, p, plev, outs, n_local, first, nlev, np_dtype):
+def check_parity(args, t, q, p, plev, outs, n_local, first, nlev, np_dtype, hyb=None):
     """GPU outputs of the timed arrays vs the oracle on 256-point windows of 32 levels."""
     tol = 1e-4 if args.dtype == "f32" else 1e-6
     wins = []
-    for lev in np.linspace(0, nlev - 1, 32).round().astype(int):
+    lo_lev = 0
+    if args.pmode == "hybrid" and args.workload != "hybrid_levels":
+        lo_lev = min(36, nlev - 1)  # above ~25 hPa the synthetic humidity is unphysical (SURVEY.md B.5)
+    for lev in np.linspace(lo_lev, nlev - 1, 32).round().astype(int):
         lo = int(lev) * INNER - first + 4321
         if 0 <= lo and lo + 256 <= n_local:
             wins.append((int(lev), lo))
@@ -320,12 +354,17 @@ def check_parity(args, t, q, p, plev, outs, n_local, first, nlev, np_dtype):
         wins = [((first + 0) // INNER, 0)]
     ht = np.concatenate([t.flat_slice(lo, lo + 256).to_host() for _, lo in wins])
     hq = np.concatenate([q.flat_slice(lo, lo + 256).to_host() for _, lo in wins])
-    if p is not None:
+    if hyb is not None:
+        from oracle import vertical_oracle as vo
+
+        pf = vo.pressure_on_hybrid_levels(hyb["Ah"].astype(np_dtype), hyb["Bh"].astype(np_dtype), hyb["sph"][4321:4321 + 256])
+        hp = np.concatenate([pf[lev] for lev, _ in wins]).astype(np_dtype)
+    elif p is not None:
         hp = np.concatenate([p.flat_slice(lo, lo + 256).to_host() for _, lo in wins])
     else:
         pl = plev.to_host()
         hp = np.concatenate([np.full(256, pl[lev], np_dtype) for lev, _ in wins])
-    want = oracle_call(args.workload, ht, hq, hp)
+    want = (hp,) if args.workload == "hybrid_levels" else oracle_call(args.workload, ht, hq, hp)
     # points whose Davies-Jones regime is decided by rounding in the reference itself are excluded
     # from the wet-bulb comparison and counted (oracle/conditioning.py)
     edge = None
@@ -351,13 +390,16 @@ def check_parity(args, t, q, p, plev, outs, n_local, first, nlev, np_dtype):
             "ok": bool(nan_mismatch == 0 and (worst <= tol or bis))}
 
 
-def traffic_from_profiles(args):
-    """HBM bytes per launch from the committed PMC passes (profiles/traffic_*.json), else null."""
+def traffic_from_profiles(args, n_local):
+    """HBM bytes per launch measured with the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
+    rocprofv3 passes of this same command, committed as profiles/traffic_latest.json), scaled to this
+    launch's share of the field; null when no PMC pass exists for the workload."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        return d.get(f"{args.workload}:{args.pmode}:{args.dtype}:{args.levels}")
+        whole = d.get(f"{args.workload}:{args.pmode}:{args.dtype}:{args.levels}")
+        return None if whole is None else whole * n_local / (args.levels * INNER)
     except Exception:
         return None
 

@@ -62,6 +62,9 @@ struct MapArgs {
   const T* aux1;                 //                                 B half-level table
 };
 
+#ifndef EKM_SCHED_SPLIT
+#define EKM_SCHED_SPLIT 0
+#endif
 #ifndef EKM_NT_LOAD
 #define EKM_NT_LOAD 1
 #endif
@@ -125,6 +128,9 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_fields(const M
           Op::template apply<T>(x, y, a.rp);
 #pragma unroll
           for (int o = 0; o < NOUT; ++o) yout[o][j] = y[o];
+#if EKM_SCHED_SPLIT
+          __builtin_amdgcn_sched_barrier(0);  // keep the per-point bodies apart: shorter live ranges
+#endif
         }
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) st_stream<T>(a.out[o] + v * V, yout[o]);

@@ -100,7 +100,7 @@ __host__ __device__ inline double synth_level_p(unsigned k, unsigned nlev) {
 
 template <class T>
 __global__ __launch_bounds__(256) void synth_fill(T* t, T* q, T* p, uint64_t first, size_t n, uint64_t inner,
-                                                 uint32_t nlev, uint64_t seed) {
+                                                 uint32_t nlev, uint64_t seed, int p_given) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const uint64_t g = first + i;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void synth_fill(T* t, T* q, T* p, uint64_t fir
     const uint64_t h1 = mix64(h0 + 1), h2 = mix64(h0 + 2), h3 = mix64(h0 + 3);
     const double pl = synth_level_p((unsigned)lev, nlev);
     // with a level-vector p (p == NULL) the point sits exactly on its level
-    const double pv = p ? pl * (1.0 + 0.05 * (2.0 * u01(h0) - 1.0)) : pl;
+    const double pv = p_given ? (double)p[i] : (p ? pl * (1.0 + 0.05 * (2.0 * u01(h0) - 1.0)) : pl);
     // Box-Muller normal, sigma = 8 K around the standard atmosphere
     const double nrm = sqrt(-2.0 * log(u01(h1))) * cos(6.283185307179586 * u01(h2));
     double tv = fmax(288.15 * pow(pv / 101325.0, 0.190263), 216.65) + 8.0 * nrm;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void synth_fill(T* t, T* q, T* p, uint64_t fir
     if (!(qv == qv)) qv = 3e-6;
     t[i] = (T)tv;
     q[i] = (T)qv;
-    if (p) p[i] = (T)pv;
+    if (p && !p_given) p[i] = (T)pv;
   }
 }
 
@@ -135,7 +135,7 @@ __global__ void synth_levels(T* pl, uint32_t nlev) {
 
 template <class T>
 static int synth_fill_launch(int dev, void* stream, T* t, T* q, T* p, uint64_t first, size_t n, uint64_t inner,
-                             uint32_t nlev, uint64_t seed) {
+                             uint32_t nlev, uint64_t seed, int p_given = 0) {
   if (n == 0) return EKM_OK;
   if (!t || !q) return set_error(EKM_ERR_ARG, "synth_fill: null t/q pointer");
   if (inner == 0 || nlev == 0) return set_error(EKM_ERR_ARG, "synth_fill: inner and nlev must be > 0");
@@ -146,7 +146,7 @@ static int synth_fill_launch(int dev, void* stream, T* t, T* q, T* p, uint64_t f
   size_t want = (n + 255) / 256, cap = (size_t)cus * 8;
   const unsigned grid = (unsigned)(want < cap ? want : cap);
   hipLaunchKernelGGL((synth_fill<T>), dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), t, q, p, first, n,
-                     inner, nlev, seed);
+                     inner, nlev, seed, p_given);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "synth_fill launch");
   return EKM_OK;
@@ -356,6 +356,16 @@ int ekm_synth_fill_f32(int dev, void* stream, float* t, float* q, float* p, uint
 int ekm_synth_fill_f64(int dev, void* stream, double* t, double* q, double* p, uint64_t first, size_t n,
                        uint64_t inner, uint32_t nlev, uint64_t seed) {
   return synth_fill_launch<double>(dev, stream, t, q, p, first, n, inner, nlev, seed);
+}
+int ekm_synth_fill_given_p_f32(int dev, void* stream, float* t, float* q, const float* p, uint64_t first, size_t n,
+                               uint64_t seed) {
+  if (!p) return set_error(EKM_ERR_ARG, "synth_fill_given_p: null p");
+  return synth_fill_launch<float>(dev, stream, t, q, const_cast<float*>(p), first, n, 1, 1, seed, 1);
+}
+int ekm_synth_fill_given_p_f64(int dev, void* stream, double* t, double* q, const double* p, uint64_t first, size_t n,
+                               uint64_t seed) {
+  if (!p) return set_error(EKM_ERR_ARG, "synth_fill_given_p: null p");
+  return synth_fill_launch<double>(dev, stream, t, q, const_cast<double*>(p), first, n, 1, 1, seed, 1);
 }
 int ekm_synth_levels_f32(int dev, void* stream, float* p_levels, uint32_t nlev) {
   return synth_levels_launch<float>(dev, stream, p_levels, nlev);

@@ -64,6 +64,8 @@ def _signatures():
         "ekm_set_tuning": ([i, i], i), "ekm_get_tuning": ([C.POINTER(i), C.POINTER(i)], i),
         "ekm_synth_fill_f32": ([i, vp, vp, vp, vp, u64, sz, u64, u32, u64], i),
         "ekm_synth_fill_f64": ([i, vp, vp, vp, vp, u64, sz, u64, u32, u64], i),
+        "ekm_synth_fill_given_p_f32": ([i, vp, vp, vp, vp, u64, sz, u64], i),
+        "ekm_synth_fill_given_p_f64": ([i, vp, vp, vp, vp, u64, sz, u64], i),
         "ekm_synth_levels_f32": ([i, vp, vp, u32], i), "ekm_synth_levels_f64": ([i, vp, vp, u32], i),
     }
     for tag, real in (("f32", C.c_float), ("f64", C.c_double)):

@@ -203,6 +203,11 @@ EKM_API int ekm_synth_fill_f32(int dev, void* stream, float* t, float* q, float*
                                uint64_t inner, uint32_t nlev, uint64_t seed);
 EKM_API int ekm_synth_fill_f64(int dev, void* stream, double* t, double* q, double* p, uint64_t first, size_t n,
                                uint64_t inner, uint32_t nlev, uint64_t seed);
+/* same distribution of t, q around a pressure field that is already on the device (e.g. hybrid levels) */
+EKM_API int ekm_synth_fill_given_p_f32(int dev, void* stream, float* t, float* q, const float* p, uint64_t first,
+                                       size_t n, uint64_t seed);
+EKM_API int ekm_synth_fill_given_p_f64(int dev, void* stream, double* t, double* q, const double* p, uint64_t first,
+                                       size_t n, uint64_t seed);
 EKM_API int ekm_synth_levels_f32(int dev, void* stream, float* p_levels, uint32_t nlev);
 EKM_API int ekm_synth_levels_f64(int dev, void* stream, double* p_levels, uint32_t nlev);
 
