@@ -94,6 +94,123 @@ __global__ __launch_bounds__(kThreads) void any_le(const T* __restrict__ sp, uns
   if (__builtin_amdgcn_ballot_w64(hit) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
+// Geopotential chain on hybrid levels, reference vertical.py:741-1190:
+//   d_k = (Rd + (Rv-Rd) q_k) t_k;  dphi_k = sum_{j>k} d_j delta_j + d_k alpha_k   (bottom-up scan)
+// fused with the producer of alpha/delta (above) so that neither they nor the pressures ever
+// touch HBM: per grid point 8 B read (t, q) + 4 B written.  One lane owns 4 (2) consecutive
+// columns and walks from the surface to the model top with the running sum and the lower
+// half-level pressure in registers; a workgroup reads/writes 4 KiB contiguous per level and field.
+// mode: 0 thickness, 1 + zs (geopotential), 2 geometric height above sea, 3 geopotential height
+// above sea, 4 geometric height above ground, 5 geopotential height above ground.
+enum { GEO_THICKNESS = 0, GEO_GEOPOTENTIAL = 1, GEO_H_GEOM_SEA = 2, GEO_H_GP_SEA = 3, GEO_H_GEOM_GROUND = 4,
+       GEO_H_GP_GROUND = 5 };
+
+template <class T>
+__global__ __launch_bounds__(kThreads) void geopotential_columns(const T* __restrict__ A, const T* __restrict__ B,
+                                                                const T* __restrict__ sp, const T* __restrict__ zs,
+                                                                const T* __restrict__ t, const T* __restrict__ q,
+                                                                unsigned long long npts, unsigned nfull,
+                                                                int top_is_zero, T alpha_top, int mode,
+                                                                T* __restrict__ out, int vec_ok) {
+  constexpr int V = VecOf<T>::N;
+  typedef typename VecOf<T>::type Vec;
+  const unsigned long long i0 = ((unsigned long long)blockIdx.x * kThreads + threadIdx.x) * V;
+  if (i0 >= npts) return;
+  const bool whole = vec_ok && (i0 + V <= npts);
+  auto get = [&](const T* base, unsigned row) {
+    const T* src = base + (unsigned long long)row * npts + i0;
+    Vec v;
+    if (whole) {
+      v = ld_stream<T>(src);
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] = (i0 + j < npts) ? src[j] : T(1);
+    }
+    return v;
+  };
+  const Vec s = get(sp, 0);
+  Vec z0, hs;
+#pragma unroll
+  for (int j = 0; j < V; ++j) z0[j] = hs[j] = T(0);
+  if (mode != GEO_THICKNESS && mode != GEO_H_GP_GROUND) z0 = get(zs, 0);
+  constexpr double g0 = 9.80665, re = 6371229.0;  // constants/constants.py
+  if (mode == GEO_H_GEOM_GROUND) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const T zz = z0[j] / T(g0);
+      hs[j] = T(re) * zz / (T(re) - zz);  // vertical.py:500-501
+    }
+  }
+
+  Vec acc;
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] = T(0);
+  Vec phn = A[nfull] + B[nfull] * s;  // lower half level of the current layer
+  for (unsigned kk = nfull; kk-- > 0;) {
+    const Vec ph = A[kk] + B[kk] * s;
+    const Vec tk = get(t, kk), qk = get(q, kk);
+    Vec o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      T d, a;
+      if (kk == 0 && top_is_zero) {
+        d = log(phn[j] / T(0.1));
+        a = alpha_top;
+      } else {
+        d = log(phn[j] / ph[j]);
+        a = T(1.0) - ph[j] / (phn[j] - ph[j]) * d;
+      }
+      const T rt = (T(k::Rd) + T(k::Rv - k::Rd) * qk[j]) * tk[j];  // thermo.py:1706, vertical.py:800-801
+      const T dphi = acc[j] + rt * a;
+      acc[j] += rt * d;
+      T r = dphi;
+      if (mode == GEO_GEOPOTENTIAL) r = dphi + z0[j];
+      if (mode == GEO_H_GEOM_SEA || mode == GEO_H_GEOM_GROUND) {
+        const T zz = (dphi + z0[j]) / T(g0);
+        r = T(re) * zz / (T(re) - zz) - hs[j];
+      }
+      if (mode == GEO_H_GP_SEA) r = (dphi + z0[j]) / T(g0);
+      if (mode == GEO_H_GP_GROUND) r = dphi / T(g0);
+      o[j] = r;
+    }
+    T* dst = out + (unsigned long long)kk * npts + i0;
+    if (whole) {
+      st_stream<T>(dst, o);
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j)
+        if (i0 + j < npts) dst[j] = o[j];
+    }
+    phn = ph;
+  }
+}
+
+template <class T>
+static int launch_geopotential(int dev, void* stream, const T* A, const T* B, const T* sp, const T* zs, const T* t,
+                               const T* q, size_t npts, uint32_t nfull, int top_is_zero, T alpha_top, int mode,
+                               T* out) {
+  if (npts == 0 || nfull == 0) return EKM_OK;
+  if (!A || !B || !sp || !t || !q || !out) return set_error(EKM_ERR_ARG, "geopotential_on_hybrid_levels: null pointer");
+  if (mode < 0 || mode > 5) return set_error(EKM_ERR_ENUM, "geopotential_on_hybrid_levels: mode=%d", mode);
+  if (mode != GEO_THICKNESS && mode != GEO_H_GP_GROUND && !zs)
+    return set_error(EKM_ERR_ARG, "geopotential_on_hybrid_levels: this mode needs the surface geopotential zs");
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  constexpr int V = VecOf<T>::N;
+  int vec_ok = (npts % V == 0);
+  for (const void* ptr : {(const void*)sp, (const void*)zs, (const void*)t, (const void*)q, (const void*)out})
+    if (ptr && reinterpret_cast<uintptr_t>(ptr) % 16) vec_ok = 0;
+  const unsigned long long nchunk = (npts + V - 1) / V;
+  const unsigned long long grid = (nchunk + kThreads - 1) / kThreads;
+  if (grid > 0x7fffffffull) return set_error(EKM_ERR_ARG, "geopotential_on_hybrid_levels: too many columns");
+  hipLaunchKernelGGL((geopotential_columns<T>), dim3((unsigned)grid), dim3(kThreads), 0,
+                     static_cast<hipStream_t>(stream), A, B, sp, zs, t, q, (unsigned long long)npts, nfull, top_is_zero,
+                     alpha_top, mode, out, vec_ok);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(EKM_ERR_HIP, "geopotential_columns launch: %s", hipGetErrorString(e));
+  return EKM_OK;
+}
+
 template <class T>
 static int launch_hybrid(int dev, void* stream, const T* A, const T* B, const T* sp, size_t npts, uint32_t nfull,
                          const int32_t* row_full, const int32_t* row_half, int top_is_zero, T alpha_top, T* full,
@@ -152,6 +269,18 @@ int ekm_pressure_on_hybrid_levels_f64(int dev, void* stream, const double* A, co
                                       double* alpha) {
   return ekm::launch_hybrid<double>(dev, stream, A, B, sp, npts, nfull, row_full, row_half, top_is_zero, alpha_top,
                                     full, half, delta, alpha);
+}
+
+int ekm_geopotential_on_hybrid_levels_f32(int dev, void* stream, const float* A, const float* B, const float* sp,
+                                          const float* zs, const float* t, const float* q, size_t npts, uint32_t nfull,
+                                          int top_is_zero, float alpha_top, int mode, float* out) {
+  return ekm::launch_geopotential<float>(dev, stream, A, B, sp, zs, t, q, npts, nfull, top_is_zero, alpha_top, mode, out);
+}
+
+int ekm_geopotential_on_hybrid_levels_f64(int dev, void* stream, const double* A, const double* B, const double* sp,
+                                          const double* zs, const double* t, const double* q, size_t npts,
+                                          uint32_t nfull, int top_is_zero, double alpha_top, int mode, double* out) {
+  return ekm::launch_geopotential<double>(dev, stream, A, B, sp, zs, t, q, npts, nfull, top_is_zero, alpha_top, mode, out);
 }
 
 int ekm_any_le_f32(int dev, void* stream, const float* sp, size_t n, float a0, float b0, float thresh, int32_t* flag) {

@@ -155,6 +155,100 @@ def pressure_on_hybrid_levels(A, B, sp, levels=None, alpha_top="ifs", output="fu
     return res[0] if len(res) == 1 else tuple(res)
 
 
+def _top_is_zero(A0, B0, sp, d_sp, dtype, npts, device, on_device):
+    """The reference's global any(p_half[0] <= 0.1) (vertical.py:680, 694)."""
+    lib, stream = _ffi.lib(), current_stream()
+    a0, b0 = float(A0), float(B0)
+    if b0 == 0.0 or npts == 0:
+        return bool(a0 <= PRESSURE_TOA)
+    if not on_device:
+        return bool(np.any(np.asarray(A0, dtype) + np.asarray(B0, dtype) * np.asarray(sp, dtype=dtype) <= PRESSURE_TOA))
+    tag, real = ("f32", C.c_float) if dtype == _F32 else ("f64", C.c_double)
+    flag = _dev_bytes(np.zeros(1, np.int32), device)
+    _ffi.check(getattr(lib, f"ekm_any_le_{tag}")(device, stream, d_sp.ptr, npts, real(a0), real(b0),
+                                                 real(PRESSURE_TOA), flag.ptr))
+    host = np.zeros(1, np.int32)
+    _ffi.check(lib.ekm_d2h(device, host.ctypes.data, flag.ptr, 4, stream))
+    _ffi.check(lib.ekm_stream_sync(device, stream))
+    return bool(host[0])
+
+
+_GEO_MODE = {"thickness": 0, "geopotential": 1, ("geometric", "sea"): 2, ("geopotential", "sea"): 3,
+             ("geometric", "ground"): 4, ("geopotential", "ground"): 5}
+
+
+def _chain(t, q, zs, A, B, sp, alpha_top, mode, vertical_axis):
+    """t, q on hybrid full levels + surface pressure -> geopotential thickness / geopotential / height in
+    ONE bottom-up pass per column (vertical.py:741-1190); alpha, delta and the half-level pressures are
+    formed on the fly and never stored."""
+    if alpha_top not in ["ifs", "arpege"]:
+        raise ValueError(f"Unknown method '{alpha_top}' for pressure calculation. Use 'ifs' or 'arpege'.")
+    A, B = np.asarray(A), np.asarray(B)
+    arrs = dict(t=t, q=q, sp=sp, zs=zs)
+    on_device = any(isinstance(v, DeviceArray) for v in arrs.values())
+    if on_device and vertical_axis != 0:
+        raise ValueError("DeviceArray input: fields are level-major, vertical_axis must be 0")
+    host = {k: (v if isinstance(v, DeviceArray) else (None if v is None else np.asarray(v))) for k, v in arrs.items()}
+    if not on_device and vertical_axis != 0:
+        host["t"], host["q"] = (np.moveaxis(host[k], vertical_axis, 0) for k in ("t", "q"))
+    parts = [v.dtype for v in host.values() if v is not None] + [A.dtype, B.dtype]
+    dtype = _F32 if np.result_type(*parts, 0.0) == _F32 else _F64
+    out_parts = [host["t"].dtype, host["q"].dtype] + ([host["zs"].dtype] if zs is not None and mode not in (0, 5) else [])
+    out_dtype = np.result_type(*out_parts, np.float32 if all(p == _F32 for p in out_parts) else 0.0)
+    shape = tuple(host["t"].shape)
+    if tuple(host["q"].shape) != shape or shape[1:] != tuple(host["sp"].shape):
+        raise ValueError(f"t {shape}, q {tuple(host['q'].shape)} must be [levels, *sp.shape] with sp {tuple(host['sp'].shape)}")
+    nlev_t, nlev = shape[0], A.shape[0] - 1
+    if nlev_t > nlev:
+        raise ValueError(f"data have {nlev_t} levels, A/B have {nlev} levels")
+    A, B = A[nlev - nlev_t:], B[nlev - nlev_t:]  # the bottom-most nlev_t layers (vertical.py:1191-1203)
+    npts = int(np.prod(shape[1:], dtype=np.int64))
+    device = next((v.device for v in host.values() if isinstance(v, DeviceArray)), current_device())
+
+    def dev(v):
+        if isinstance(v, DeviceArray) and v.dtype == dtype:
+            return v
+        return DeviceArray.from_host(np.ascontiguousarray(np.asarray(v), dtype=dtype), device)
+
+    d = {k: (dev(v) if v is not None else None) for k, v in host.items()}
+    d_a, d_b = dev(A), dev(B)
+    top = _top_is_zero(A[0], B[0], host["sp"], d["sp"], dtype, npts, device, isinstance(host["sp"], DeviceArray))
+    a_top = float(np.log(2)) if alpha_top == "ifs" else 1.0
+    out = DeviceArray.empty(shape, dtype, device)
+    lib = _ffi.lib()
+    tag, real = ("f32", C.c_float) if dtype == _F32 else ("f64", C.c_double)
+    _ffi.check(getattr(lib, f"ekm_geopotential_on_hybrid_levels_{tag}")(
+        device, current_stream(), d_a.ptr, d_b.ptr, d["sp"].ptr, d["zs"].ptr if d["zs"] is not None else None,
+        d["t"].ptr, d["q"].ptr, npts, nlev_t, int(top), real(a_top), mode, out.ptr))
+    if on_device:
+        _ffi.check(lib.ekm_stream_sync(device, current_stream()))
+        return out
+    res = out.to_host().astype(out_dtype, copy=False)
+    out.free()
+    if vertical_axis != 0:
+        res = np.moveaxis(res, 0, vertical_axis)
+    return res
+
+
+def relative_geopotential_thickness_on_hybrid_levels(t, q, A, B, sp, alpha_top="ifs", vertical_axis=0):
+    """Geopotential thickness between the surface and the hybrid full levels (vertical.py:894-994)."""
+    return _chain(t, q, None, A, B, sp, alpha_top, _GEO_MODE["thickness"], vertical_axis)
+
+
+def geopotential_on_hybrid_levels(t, q, zs, A, B, sp, alpha_top="ifs", vertical_axis=0):
+    """Geopotential on hybrid full levels (vertical.py:997-1069)."""
+    return _chain(t, q, zs, A, B, sp, alpha_top, _GEO_MODE["geopotential"], vertical_axis)
+
+
+def height_on_hybrid_levels(t, q, zs, A, B, sp, alpha_top="ifs", h_type="geometric", h_reference="ground",
+                            vertical_axis=0):
+    """Geometric / geopotential height above sea level / ground on hybrid full levels (vertical.py:1072-1188)."""
+    if h_reference not in ["sea", "ground"]:
+        raise ValueError(f"Unknown '{h_reference=}'. Use 'sea' or 'ground'.")
+    key = ("geometric" if h_type == "geometric" else "geopotential", h_reference)
+    return _chain(t, q, zs, A, B, sp, alpha_top, _GEO_MODE[key], vertical_axis)
+
+
 class HybridPressure:
     """Pressure on hybrid full levels given by its definition, p_k(x) = p_half[k] + 0.5*(p_half[k+1]-p_half[k])
     with p_half[h] = A[h] + B[h]*sp(x), for use in place of a pressure field in ekm_hip.thermo calls on

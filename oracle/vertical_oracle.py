@@ -77,3 +77,85 @@ def pressure_on_hybrid_levels(A, B, sp, levels=None, alpha_top="ifs", output="fu
     if vertical_axis != 0 and res[0].ndim > 1:
         res = [np.moveaxis(r, 0, vertical_axis) for r in res]
     return res[0] if len(res) == 1 else tuple(res)
+
+
+# --- geopotential chain on hybrid levels --------------------------------
+# vertical.py:330-356, 472-502, 741-1190.  Constants: constants/constants.py (g, R_earth, Rd, Rv).
+G0 = 9.80665
+R_EARTH = 6371229
+RD = 287.0597
+RV = 461.51
+
+
+def geopotential_height_from_geopotential(z):  # vertical.py:330-356
+    return z / G0
+
+
+def geometric_height_from_geopotential(z, R_earth=R_EARTH):  # vertical.py:472-502
+    z = z / G0
+    return R_earth * z / (R_earth - z)
+
+
+def _thickness(t, q, alpha, delta):  # vertical.py:741-768
+    R = RD + (RV - RD) * q  # thermo.specific_gas_constant (thermo.py:1706)
+    d = R * t
+    dphi_half = np.cumulative_sum(np.flip(d[1:, ...] * delta[1:, ...], axis=0), axis=0)
+    dphi_half = np.flip(dphi_half, axis=0)
+    dphi = np.zeros_like(d)
+    dphi[:-1, ...] = dphi_half + d[:-1, ...] * alpha[:-1, ...]
+    dphi[-1, ...] = d[-1, ...] * alpha[-1, ...]
+    return dphi
+
+
+def relative_geopotential_thickness_on_hybrid_levels_from_alpha_delta(t, q, alpha, delta, vertical_axis=0):
+    # vertical.py:815-891
+    alpha, delta, t, q = (np.asarray(x) for x in (alpha, delta, t, q))
+    if vertical_axis != 0:
+        alpha, delta, t, q = (np.moveaxis(x, vertical_axis, 0) for x in (alpha, delta, t, q))
+    dphi = _thickness(t, q, alpha, delta)
+    if vertical_axis != 0:
+        dphi = np.moveaxis(dphi, 0, vertical_axis)
+    return dphi
+
+
+def _hybrid_subset(data, A, B, vertical_axis=0):  # vertical.py:1191-1203
+    nlev_t = data.shape[vertical_axis]
+    nlev = A.shape[0] - 1
+    if nlev_t != nlev:
+        return list(range(nlev - nlev_t + 1, nlev + 1))
+    return None
+
+
+def relative_geopotential_thickness_on_hybrid_levels(t, q, A, B, sp, alpha_top="ifs", vertical_axis=0):
+    # vertical.py:894-994
+    A, B, sp, t, q = (np.asarray(x) for x in (A, B, sp, t, q))
+    levels = _hybrid_subset(t, A, B, vertical_axis)
+    alpha, delta = pressure_on_hybrid_levels(A, B, sp, alpha_top=alpha_top, levels=levels, output=("alpha", "delta"))
+    if vertical_axis != 0:
+        alpha, delta, t, q = (np.moveaxis(x, vertical_axis, 0) for x in (alpha, delta, t, q))
+    dphi = _thickness(t, q, alpha, delta)
+    if vertical_axis != 0:
+        dphi = np.moveaxis(dphi, 0, vertical_axis)
+    return dphi
+
+
+def geopotential_on_hybrid_levels(t, q, zs, A, B, sp, alpha_top="ifs", vertical_axis=0):  # vertical.py:997-1069
+    z = relative_geopotential_thickness_on_hybrid_levels(t, q, A, B, sp, vertical_axis=vertical_axis,
+                                                         alpha_top=alpha_top)
+    return z + np.asarray(zs)
+
+
+def height_on_hybrid_levels(t, q, zs, A, B, sp, alpha_top="ifs", h_type="geometric", h_reference="ground",
+                            vertical_axis=0):  # vertical.py:1072-1188
+    if h_reference not in ["sea", "ground"]:
+        raise ValueError(f"Unknown '{h_reference=}'. Use 'sea' or 'ground'.")
+    zt = relative_geopotential_thickness_on_hybrid_levels(t, q, A, B, sp, alpha_top=alpha_top,
+                                                          vertical_axis=vertical_axis)
+    if h_reference == "sea":
+        z = zt + np.asarray(zs)
+        return geometric_height_from_geopotential(z) if h_type == "geometric" else geopotential_height_from_geopotential(z)
+    if h_type == "geometric":
+        zs = np.asarray(zs)
+        h_surf = geometric_height_from_geopotential(zs)
+        return geometric_height_from_geopotential(zt + zs) - h_surf
+    return geopotential_height_from_geopotential(zt)

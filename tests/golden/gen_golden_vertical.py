@@ -78,6 +78,46 @@ def main():
         for name, r in zip(c["output"], res):
             store[f"{c['id']}.{name}"] = np.asarray(r)
         manifest.append(c)
+    # ---- geopotential chain (vertical.py:741-1190) ----
+    for k in ("t", "q", "z"):
+        store[f"fixture.{k}"] = np.asarray(getattr(core, k))
+    spec = importlib.util.spec_from_file_location("hh", os.path.join(REF, "tests", "vertical", "_hybrid_height_data.py"))
+    hh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hh)
+    for k in ("p_surf", "z_surf", "t", "q", "h_geometric_sea", "h_geometric_ground", "h_geopotential_sea",
+              "h_geopotential_ground"):
+        store[f"hfix.{k}"] = np.asarray(getattr(hh, k))
+    A137, B137 = store["coef.137.A"], store["coef.137.B"]
+    ncol = 61
+    sp = rng.uniform(52000.0, 104000.0, ncol)
+    zs = rng.uniform(-50.0, 30000.0, ncol)
+    pf = ref.pressure_on_hybrid_levels(A137, B137, sp)
+    tt = np.maximum(288.15 * (np.maximum(pf, 1.0) / 101325.0) ** 0.190263, 190.0) + rng.normal(0, 6, pf.shape)
+    qq = np.clip(rng.uniform(0, 1, pf.shape) ** 3 * 0.02 * (pf / 101325.0) ** 2, 1e-7, 0.03)
+    store["chain.sp"], store["chain.zs"], store["chain.t"], store["chain.q"] = sp, zs, tt, qq
+    chain = []
+    for dt in ("f64", "f32"):
+        npdt = np.float32 if dt == "f32" else np.float64
+        a_, b_ = (A137.astype(npdt), B137.astype(npdt)) if dt == "f32" else (A137, B137)
+        t_, q_, sp_, zs_ = (x.astype(npdt) for x in (tt, qq, sp, zs))
+        for nl in (137, 47, 1):
+            cid = f"chain.{dt}.n{nl}"
+            ts, qs = t_[137 - nl:], q_[137 - nl:]
+            store[f"{cid}.thickness"] = ref.relative_geopotential_thickness_on_hybrid_levels(ts, qs, a_, b_, sp_)
+            store[f"{cid}.geopotential"] = ref.geopotential_on_hybrid_levels(ts, qs, zs_, a_, b_, sp_)
+            for ht in ("geometric", "geopotential"):
+                for hr in ("sea", "ground"):
+                    store[f"{cid}.h_{ht}_{hr}"] = ref.height_on_hybrid_levels(ts, qs, zs_, a_, b_, sp_, h_type=ht,
+                                                                              h_reference=hr)
+            chain.append(dict(id=cid, dtype=dt, nlev=nl))
+        al, de = ref.pressure_on_hybrid_levels(a_, b_, sp_, output=("alpha", "delta"))
+        store[f"chain.{dt}.from_alpha_delta"] = ref.relative_geopotential_thickness_on_hybrid_levels_from_alpha_delta(
+            t_, q_, al, de)
+        store[f"chain.{dt}.arpege"] = ref.relative_geopotential_thickness_on_hybrid_levels(t_, q_, a_, b_, sp_,
+                                                                                          alpha_top="arpege")
+        # (vertical_axis != 0 is not recorded: the reference moves the already level-first alpha/delta
+        #  as well, vertical.py:981-986, and fails to broadcast for non-square input)
+    store["chain_manifest"] = np.frombuffer(json.dumps(chain).encode(), dtype=np.uint8)
     store["manifest"] = np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8)
     path = os.path.join(HERE, "vertical_golden.npz")
     np.savez_compressed(path, **store)

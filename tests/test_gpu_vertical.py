@@ -109,3 +109,46 @@ def test_hybrid_pressure_operand(ek, tag, dt):
     assert_parity(th.to_host(), orc.potential_temperature(t, pfull), tag, "device-resident hybrid p")
     with pytest.raises(ValueError):
         ek.thermo.potential_temperature(t[:5], hp)
+
+
+from test_vertical_oracle import CHAIN, chain_args, chain_calls  # noqa: E402
+
+
+@pytest.mark.parametrize("c", CHAIN, ids=[c["id"] for c in CHAIN])
+def test_geopotential_chain_golden(ek, c):
+    """Fused column scan (t, q, sp -> thickness / geopotential / heights) vs the reference's outputs:
+    fp64 1e-6 relative; fp32 1e-4 relative against the reference's fp32 result (+ 0.01 m / m2s-2
+    absolute for the near-surface values that cancel against the surface terms)."""
+    args = chain_args(c)
+    for k, v in chain_calls(ek.vertical, *args).items():
+        w = G[f"{c['id']}.{k}"]
+        assert v.dtype == w.dtype and v.shape == w.shape, (c["id"], k, v.dtype, w.dtype)
+        if c["dtype"] == "f64":
+            assert np.allclose(v, w, rtol=1e-6, atol=1e-9), (c["id"], k, np.abs(v - w).max())
+        else:
+            assert np.allclose(v, w, rtol=1e-4, atol=1e-2), (c["id"], k, np.abs(v - w).max())
+
+
+def test_geopotential_chain_fixtures_and_device(ek):
+    A, B, sp, t, q = (G[f"fixture.{k}"] for k in ("A", "B", "p_surf", "t", "q"))
+    z = ek.vertical.relative_geopotential_thickness_on_hybrid_levels(t, q, A, B, sp)
+    assert np.allclose(z, G["fixture.z"], atol=1e-8, rtol=1e-6)
+    z = ek.vertical.geopotential_on_hybrid_levels(t[90:], q[90:], np.zeros(2), A, B, sp)
+    assert np.allclose(z, G["fixture.z"][90:], atol=1e-8, rtol=1e-6)
+    A137, B137 = G["coef.137.A"], G["coef.137.B"]
+    sp, zs, t, q = (G[f"hfix.{k}"] for k in ("p_surf", "z_surf", "t", "q"))
+    for ht in ("geometric", "geopotential"):
+        for hr in ("sea", "ground"):
+            h = ek.vertical.height_on_hybrid_levels(t, q, zs, A137, B137, sp, h_type=ht, h_reference=hr)
+            assert np.allclose(h, G[f"hfix.h_{ht}_{hr}"], atol=1e-8, rtol=1e-6), (ht, hr)
+    # device-resident, fp32, ragged column count
+    from oracle import vertical_oracle as vo
+
+    c = dict(dtype="f32", nlev=137)
+    t, q, zs, A, B, sp = chain_args(c)
+    out = ek.vertical.geopotential_on_hybrid_levels(ek.to_device(t), ek.to_device(q), ek.to_device(zs), A, B,
+                                                    ek.to_device(sp))
+    assert isinstance(out, ek.DeviceArray) and out.shape == t.shape
+    assert np.allclose(out.to_host(), vo.geopotential_on_hybrid_levels(t, q, zs, A, B, sp), rtol=1e-4, atol=1e-2)
+    with pytest.raises(ValueError, match="h_reference"):
+        ek.vertical.height_on_hybrid_levels(t, q, zs, A, B, sp, h_reference="moon")

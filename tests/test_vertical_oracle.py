@@ -55,3 +55,50 @@ def test_oracle_errors():
         vo.pressure_on_hybrid_levels(A, B, sp, levels=[0])
     with pytest.raises(ValueError, match="At least one"):
         vo.pressure_on_hybrid_levels(A, B, sp, output=[])
+
+
+CHAIN = json.loads(bytes(G["chain_manifest"]).decode())
+
+
+def chain_args(c):
+    dt = np.float32 if c["dtype"] == "f32" else np.float64
+    A, B = G["coef.137.A"], G["coef.137.B"]
+    if c["dtype"] == "f32":
+        A, B = A.astype(dt), B.astype(dt)
+    t, q, sp, zs = (G[f"chain.{k}"].astype(dt) for k in ("t", "q", "sp", "zs"))
+    nl = c["nlev"]
+    return t[137 - nl:], q[137 - nl:], zs, A, B, sp
+
+
+def chain_calls(mod, t, q, zs, A, B, sp):
+    out = {"thickness": mod.relative_geopotential_thickness_on_hybrid_levels(t, q, A, B, sp),
+           "geopotential": mod.geopotential_on_hybrid_levels(t, q, zs, A, B, sp)}
+    for ht in ("geometric", "geopotential"):
+        for hr in ("sea", "ground"):
+            out[f"h_{ht}_{hr}"] = mod.height_on_hybrid_levels(t, q, zs, A, B, sp, h_type=ht, h_reference=hr)
+    return out
+
+
+@pytest.mark.parametrize("c", CHAIN, ids=[c["id"] for c in CHAIN])
+def test_chain_oracle_bit_exact(c):
+    for k, v in chain_calls(vo, *chain_args(c)).items():
+        w = G[f"{c['id']}.{k}"]
+        assert v.dtype == w.dtype and np.array_equal(v, w, equal_nan=True), (c["id"], k)
+
+
+def test_chain_oracle_vs_reference_fixtures():
+    """tests/vertical/test_array_vertical.py:385-523 there (fp64: atol 1e-8, rtol 1e-6)."""
+    A, B, sp, t, q = (G[f"fixture.{k}"] for k in ("A", "B", "p_surf", "t", "q"))
+    z = vo.relative_geopotential_thickness_on_hybrid_levels(t, q, A, B, sp)
+    assert np.allclose(z, G["fixture.z"], atol=1e-8, rtol=1e-6)
+    assert np.allclose(vo.relative_geopotential_thickness_on_hybrid_levels(t[90:], q[90:], A, B, sp), G["fixture.z"][90:],
+                       atol=1e-8, rtol=1e-6)
+    al, de = vo.pressure_on_hybrid_levels(A, B, sp, output=("alpha", "delta"))
+    assert np.allclose(vo.relative_geopotential_thickness_on_hybrid_levels_from_alpha_delta(t, q, al, de), G["fixture.z"],
+                       atol=1e-8, rtol=1e-6)
+    A137, B137 = G["coef.137.A"], G["coef.137.B"]
+    sp, zs, t, q = (G[f"hfix.{k}"] for k in ("p_surf", "z_surf", "t", "q"))
+    for ht in ("geometric", "geopotential"):
+        for hr in ("sea", "ground"):
+            h = vo.height_on_hybrid_levels(t, q, zs, A137, B137, sp, h_type=ht, h_reference=hr)
+            assert np.allclose(h, G[f"hfix.h_{ht}_{hr}"], atol=1e-8, rtol=1e-6), (ht, hr)

@@ -226,6 +226,20 @@ EKM_API int ekm_pressure_on_hybrid_levels_f64(int dev, void* stream, const doubl
                                               size_t npts, uint32_t nfull, const int32_t* row_full,
                                               const int32_t* row_half, int top_is_zero, double alpha_top, double* full,
                                               double* half, double* delta, double* alpha);
+/* Geopotential chain on hybrid levels, fused with the producer of alpha/delta: reference
+ * vertical/array/vertical.py:741-1190 (relative_geopotential_thickness_on_hybrid_levels,
+ * geopotential_on_hybrid_levels, height_on_hybrid_levels).  t, q, out: [nfull, npts] level-major;
+ * A, B: the nfull+1 half-level coefficients of those levels; zs: surface geopotential (may be NULL
+ * for modes 0 and 5).  mode: 0 thickness, 1 geopotential (+zs), 2 geometric height above sea,
+ * 3 geopotential height above sea, 4 geometric height above ground, 5 geopotential height above ground. */
+EKM_API int ekm_geopotential_on_hybrid_levels_f32(int dev, void* stream, const float* A, const float* B,
+                                                  const float* sp, const float* zs, const float* t, const float* q,
+                                                  size_t npts, uint32_t nfull, int top_is_zero, float alpha_top,
+                                                  int mode, float* out);
+EKM_API int ekm_geopotential_on_hybrid_levels_f64(int dev, void* stream, const double* A, const double* B,
+                                                  const double* sp, const double* zs, const double* t, const double* q,
+                                                  size_t npts, uint32_t nfull, int top_is_zero, double alpha_top,
+                                                  int mode, double* out);
 /* *flag |= any(a0 + b0*sp[i] <= thresh); *flag must be zeroed by the caller (ekm_memset) */
 EKM_API int ekm_any_le_f32(int dev, void* stream, const float* sp, size_t n, float a0, float b0, float thresh,
                            int32_t* flag);
