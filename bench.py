@@ -48,6 +48,8 @@ WORKLOADS = {
     "ept": ("ept_from_specific_humidity", 3, 1, 16, "theta_e (ifs)"),
     # the producer of p; reads sp once (1/137 of 4 B/pt), writes p_full
     "hybrid_levels": ("pressure_on_hybrid_levels", 0, 1, 4, "p_full on hybrid levels from sp (A, B tables)"),
+    # t, q, sp, zs -> geopotential on model levels in one fused column scan
+    "geopotential": ("geopotential_on_hybrid_levels", 2, 1, 12, "geopotential on hybrid levels (fused alpha/delta + scan)"),
 }
 
 
@@ -229,6 +231,8 @@ def main():
         plev = DeviceArray.empty((nlev,), np_dtype, dev)
         _ffi.check(getattr(lib, f"ekm_synth_levels_{args.dtype}")(dev, None, plev.ptr, nlev))
         hyb = None
+        if args.workload == "geopotential":
+            args.pmode = "hybrid"
         if args.pmode == "hybrid" or args.workload == "hybrid_levels":
             # IFS L137 half-level tables (data recorded from the reference's conf/ifs_levels_conf.json)
             assert first == 0 and nlev <= 137, "hybrid mode: whole fields only"
@@ -270,9 +274,14 @@ def main():
                     "relative_humidity_from_specific_humidity": (op_t, op_q, op_p),
                     "ept_from_specific_humidity": (op_t, op_q, op_p),
                     "potential_temperature": (op_t, op_p), "saturation_vapour_pressure": (op_t,),
-                    "pressure_on_hybrid_levels": ()}[entry]
+                    "pressure_on_hybrid_levels": (), "geopotential_on_hybrid_levels": ()}[entry]
         ints = {"wetbulb": (0, 1), "wetbulb_bisect": (0, 0), "svp": (0,), "ept": (0,)}.get(args.workload, ())
         cargs = [dev, None] + [C.byref(o) for o in operands] + list(ints) + [o.ptr for o in outs] + [n_local]
+        if args.workload == "geopotential":
+            zs_host = np.maximum(0.0, (101325.0 - hyb["sph"].astype(np.float64)) * 8.4).astype(np_dtype)  # ~ g*z of the orography
+            hyb["zs"], hyb["zsh"] = DeviceArray.from_host(zs_host, dev), zs_host
+            cargs = [dev, None, hyb["A"].ptr, hyb["B"].ptr, hyb["sp"].ptr, hyb["zs"].ptr, t.ptr, q.ptr, INNER, nlev, 1,
+                     float(np.log(2)), 1, outs[0].ptr]
         if args.workload == "hybrid_levels":
             cargs = [dev, None, hyb["A"].ptr, hyb["B"].ptr, hyb["sp"].ptr, INNER, nlev, None, None, 1,
                      float(np.log(2)), outs[0].ptr, None, None, None]
@@ -342,6 +351,19 @@ def main():
 def check_parity(args, t, q, p, plev, outs, n_local, first, nlev, np_dtype, hyb=None):
     """GPU outputs of the timed arrays vs the oracle on 256-point windows of 32 levels."""
     tol = 1e-4 if args.dtype == "f32" else 1e-6
+    if args.workload == "geopotential":  # whole columns: 64 columns x all levels
+        from oracle import vertical_oracle as vo
+
+        c0, nc = 4321, 64
+        col = lambda a: np.stack([a.flat_slice(k * INNER + c0, k * INNER + c0 + nc).to_host() for k in range(nlev)])  # noqa: E731
+        want = vo.geopotential_on_hybrid_levels(col(t), col(q), hyb["zsh"][c0:c0 + nc], hyb["Ah"].astype(np_dtype),
+                                                hyb["Bh"].astype(np_dtype), hyb["sph"][c0:c0 + nc])
+        got = col(outs[0]).astype(np.float64)
+        with np.errstate(all="ignore"):
+            r = np.abs(got - want) / np.maximum(np.abs(want), 100.0)  # relative, with a 100 m2/s2 floor near the surface
+        nanmm = int((np.isnan(got) != np.isnan(want)).sum())
+        return {"points": int(got.size), "max_rel_err": float(np.nanmax(r)), "nan_mismatch": nanmm, "tolerance": tol,
+                "excluded_regime_boundary_points": 0, "ok": bool(nanmm == 0 and np.nanmax(r) <= tol)}
     wins = []
     lo_lev = 0
     if args.pmode == "hybrid" and args.workload != "hybrid_levels":
