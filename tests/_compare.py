@@ -73,7 +73,7 @@ def newton_regime_boundary(func, inputs, kwargs, thresh):
     return conditioning.newton_regime_boundary(func, inputs, kwargs, thresh)
 
 
-def assert_parity(got, want, tag, what, bisect=False, rtol=None, unstable=None, ref64=None):
+def assert_parity(got, want, tag, what, bisect=False, rtol=None, unstable=None, ref64=None, max_relaxed=None):
     """`ref64` (fp32 comparisons only): the reference's fp64 result on the same fp32 inputs.  Where
     the reference's own fp32 output sits delta away from it (an ill-conditioned point of the
     reference's algorithm, e.g. the Bolton-35 Newton step near p = p0), a differently rounded fp32
@@ -93,7 +93,8 @@ def assert_parity(got, want, tag, what, bisect=False, rtol=None, unstable=None, 
     if not bisect and ref64 is not None:
         bar = np.maximum(rtol, 4.0 * rel_err(want, ref64))
         relaxed = int((bar > rtol).sum())
-        assert relaxed <= max(3, 1e-4 * r.size), f"{what}: {relaxed} ill-conditioned points in the reference"
+        allowed = max(3, 1e-4 * r.size) if max_relaxed is None else max_relaxed
+        assert relaxed <= allowed, f"{what}: {relaxed} ill-conditioned points in the reference"
         bad = r > bar
         assert not bad.any(), f"{what}: rel err {r[bad].max():.3e} beyond max({rtol:g}, 4*delta) at {np.flatnonzero(bad)[:4]}"
         return float(r[bar <= rtol].max()) if (bar <= rtol).any() else 0.0

@@ -164,6 +164,80 @@ def test_synthetic_vs_oracle(ek, orc, slab, tag, func, args, kwargs):
     print(f"{func} {kwargs} {tag}: max rel err {worst:.2e}")
 
 
+def _all_variants():
+    """(function, argument names, kwargs) for all 39 functions and every phase / method variant."""
+    sys_path_entry = __import__("os").path.join(__import__("os").path.dirname(__file__), "golden")
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_case_table", __import__("os").path.join(sys_path_entry, "_case_table.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.case_table()
+
+
+ALL = _all_variants()
+
+
+@pytest.fixture(scope="module")
+def pool():
+    """A 16-level x 2048-point synthetic column set with every derived input the functions take."""
+    from oracle import synthetic
+    from oracle import thermo_oracle as o
+
+    out = {}
+    for tag, dt in (("f32", np.float32), ("f64", np.float64)):
+        t, q, p, _ = synthetic.make_fields(16, 2048, dtype=np.float64, seed=77)
+        t, q, p = t.ravel(), q.ravel(), p.ravel()
+        rng = np.random.default_rng(5)
+        td = np.minimum(o.dewpoint_from_specific_humidity(q, p), t - rng.uniform(0.0, 0.5, t.shape))
+        base = dict(t=t, q=q, p=p, td=td, r=o.relative_humidity_from_specific_humidity(t, q, p))
+        d = {k: v.astype(dt) for k, v in base.items()}
+        d["tc"] = (d["t"] - dt(273.16)).astype(dt)
+        d["w"] = (d["q"] / (1 - d["q"])).astype(dt)
+        d["e"] = o.vapour_pressure_from_specific_humidity(d["q"], d["p"]).astype(dt)
+        d["es"] = o.saturation_vapour_pressure(d["t"]).astype(dt)
+        d["th"] = o.potential_temperature(d["t"], d["p"]).astype(dt)
+        d["ept"] = o.ept_from_specific_humidity(d["t"], d["q"], d["p"]).astype(dt)
+        d["t2"] = (d["t"] - dt(10.0)).astype(dt)
+        d["p2"] = (d["p"] * dt(0.8)).astype(dt)
+        out[tag] = d
+    return out
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("func,args,kwargs", ALL, ids=[f"{c[0]}-{'-'.join(str(v) for v in c[2].values())}" for c in ALL])
+def test_every_function_on_synthetic_columns(ek, orc, pool, tag, func, args, kwargs):
+    """All 39 functions x every variant on 32768 physical points, GPU vs oracle in the same dtype."""
+    ins = [pool[tag][a] for a in args]
+    got = _outs(getattr(ek.thermo, func)(*ins, **kwargs))
+    want = _outs(getattr(orc, func)(*[a.copy() for a in ins], **kwargs))
+    tm = kwargs.get("t_method")
+    for k, (g_, w_) in enumerate(zip(got, want)):
+        unstable = ref64 = None
+        if tm == "bisect":
+            unstable = bisect_sign_noise(orc, func, ins, kwargs, 3e-6 if tag == "f32" else 1e-14)
+            if tag == "f32":
+                w64 = _outs(getattr(orc, func)(*[a.astype(np.float64) for a in ins], **kwargs))[k]
+                unstable |= bisect_unstable(w_, w64)
+        elif tm == "newton":
+            unstable = newton_regime_boundary(func, ins, kwargs, 1e-5 if tag == "f32" else 1e-13)
+            if tag == "f32":
+                ref64 = _outs(getattr(orc, func)(*[a.astype(np.float64) for a in ins], **kwargs))[k]
+        allowed = None
+        if tm == "newton" and "potential" in func:
+            # theta_w by Newton follows the moist adiabat down to 1000 hPa.  For the stratospheric levels
+            # of the column theta_e is 500-2000 K, far outside the Davies-Jones fit (wet-bulb guesses of
+            # +300 C, es >> p): the reference's own fp32 and fp64 results scatter there.  Compare where
+            # theta_w is defined for the atmosphere: theta_e <= 450 K.
+            hot = pool["f64"]["ept"] > 450.0
+            keep = ~(hot | (unstable if unstable is not None else False))
+            g_, w_ = g_[keep], w_[keep]
+            ref64 = ref64[keep] if ref64 is not None else None
+            unstable, allowed = None, 0.01 * g_.size
+        assert_parity(g_, w_, tag, f"{func} {kwargs} {tag}", bisect=tm == "bisect", unstable=unstable, ref64=ref64,
+                      max_relaxed=allowed)
+
+
 @pytest.mark.parametrize("tag", ["f32", "f64"])
 @pytest.mark.parametrize("method", ["ifs", "bolton35", "bolton39"])
 def test_synthetic_bisect_vs_oracle(ek, orc, slab, tag, method):
