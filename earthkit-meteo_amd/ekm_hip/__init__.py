@@ -14,6 +14,7 @@ from .device import (  # noqa: F401
     DeviceArray,
     current_device,
     device_count,
+    empty_cache,
     set_device,
     set_stream,
     shard_bounds,

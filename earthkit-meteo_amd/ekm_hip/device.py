@@ -58,20 +58,85 @@ def synchronize(dev=None):
     _ffi.check(_ffi.lib().ekm_sync(current_device() if dev is None else dev))
 
 
-class _Allocation:
-    """Owns one hipMalloc block; freed when the last view goes away."""
+class _BlockCache:
+    """Size-bucketed free list of device blocks (per device and stream).
 
-    __slots__ = ("ptr", "nbytes", "device", "__weakref__")
+    hipMalloc / hipFree cost 50-500 us each and hipFree synchronises the device; a thermo call on
+    NumPy input needs one block per operand and per output, so small and medium calls are dominated
+    by them.  Freed blocks are kept (up to `limit` bytes per device) and handed out again for
+    requests of the same bucket.  Blocks are reused only on the stream they were last used on, so
+    stream order alone makes reuse safe.
+    """
+
+    def __init__(self):
+        self.free = {}      # (device, stream, bucket) -> [ptr, ...]
+        self.bytes = {}     # device -> cached bytes
+        self.limit = int(os.environ.get("EKM_CACHE_BYTES", str(16 << 30)))
+        self.lock = threading.Lock()
+
+    @staticmethod
+    def bucket(nbytes):
+        nbytes = max(int(nbytes), 256)
+        if nbytes <= (1 << 20):
+            return 1 << (nbytes - 1).bit_length()            # powers of two up to 1 MiB
+        step = 1 << 20
+        return (nbytes + step - 1) // step * step             # then multiples of 1 MiB
+
+    def take(self, device, stream, bucket):
+        with self.lock:
+            lst = self.free.get((device, stream, bucket))
+            if lst:
+                self.bytes[device] -= bucket
+                return lst.pop()
+        return None
+
+    def give(self, device, stream, bucket, ptr):
+        with self.lock:
+            if self.bytes.get(device, 0) + bucket > self.limit:
+                return False
+            self.free.setdefault((device, stream, bucket), []).append(ptr)
+            self.bytes[device] = self.bytes.get(device, 0) + bucket
+            return True
+
+    def drain(self):
+        with self.lock:
+            items, self.free, self.bytes = self.free, {}, {}
+        for (device, _stream, _bucket), ptrs in items.items():
+            for ptr in ptrs:
+                _ffi.check(_ffi.lib().ekm_free(device, ptr))
+
+
+_cache = _BlockCache()
+
+
+def empty_cache():
+    """Return every cached device block to HIP (like torch.cuda.empty_cache)."""
+    _cache.drain()
+
+
+class _Allocation:
+    """Owns one device block; returned to the block cache when the last view goes away."""
+
+    __slots__ = ("ptr", "nbytes", "device", "stream", "bucket", "__weakref__")
 
     def __init__(self, nbytes, device):
-        out = C.c_void_p()
-        _ffi.check(_ffi.lib().ekm_malloc(device, nbytes, C.byref(out)))
-        self.ptr, self.nbytes, self.device = out.value, nbytes, device
+        self.device, self.nbytes, self.stream = device, nbytes, current_stream()
+        self.bucket = _BlockCache.bucket(nbytes)
+        ptr = _cache.take(device, self.stream, self.bucket)
+        if ptr is None:
+            out = C.c_void_p()
+            rc = _ffi.lib().ekm_malloc(device, self.bucket, C.byref(out))
+            if rc < 0:  # out of memory: give the cached blocks back and retry once
+                _cache.drain()
+                _ffi.check(_ffi.lib().ekm_malloc(device, self.bucket, C.byref(out)))
+            ptr = out.value
+        self.ptr = ptr
 
     def free(self):
         if self.ptr:
             ptr, self.ptr = self.ptr, None
-            _ffi.check(_ffi.lib().ekm_free(self.device, ptr))
+            if not _cache.give(self.device, self.stream, self.bucket, ptr):
+                _ffi.check(_ffi.lib().ekm_free(self.device, ptr))
 
     def __del__(self):
         try:
