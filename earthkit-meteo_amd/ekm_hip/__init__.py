@@ -15,6 +15,7 @@ from .device import (  # noqa: F401
     current_device,
     device_count,
     empty_cache,
+    multi_gpu,
     set_device,
     set_stream,
     shard_bounds,

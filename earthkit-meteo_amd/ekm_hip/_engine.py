@@ -116,7 +116,67 @@ class _Plan:
 
 
 def run(name, args, ints=(), eps=None, dtype=None):
-    """Launch entry point `name` on `args`; returns a tuple of outputs."""
+    """Launch entry point `name` on `args`; returns a tuple of outputs.  Inside `ekm_hip.multi_gpu()`
+    NumPy inputs are split along their leading axis across the selected GPUs (one host thread each)."""
+    from .device import current_devices
+
+    devs = current_devices()
+    if devs and len(devs) > 1 and not any(isinstance(a, (DeviceArray, HybridPressure)) for a in args):
+        sharded = _run_sharded(name, args, ints, eps, devs)
+        if sharded is not None:
+            return sharded
+    return _run_single(name, args, ints, eps, dtype)
+
+
+def leading_axis_bounds(n0, nshards):
+    """Contiguous [lo, hi) ranges of a leading axis of length n0 for nshards GPUs (sizes differ by <= 1)."""
+    base, extra = divmod(n0, nshards)
+    out, lo = [], 0
+    for r in range(nshards):
+        hi = lo + base + (1 if r < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def _run_sharded(name, args, ints, eps, devs):
+    """Grid points are independent: cut the broadcast result along its leading axis into one contiguous
+    block per GPU (for [level, lat, lon] fields: ~17 whole levels each on 8 GPUs), give every operand that
+    spans that axis the matching slice and every other operand (scalars, trailing-axis vectors) whole,
+    and run the blocks concurrently, one host thread per device, straight into slices of the result."""
+    import threading
+
+    from .device import set_device
+
+    host = [np.asarray(a) for a in args]
+    shape = tuple(np.broadcast_shapes(*[h.shape for h in host]))
+    if len(shape) == 0 or shape[0] < len(devs):
+        return None
+    out_dtype, _ = _result_dtype(args)
+    nout = len(OPS[name][1])
+    outs = [np.empty(shape, out_dtype) for _ in range(nout)]
+    bounds = [b for b in leading_axis_bounds(shape[0], len(devs)) if b[1] > b[0]]
+    errors = []
+
+    def work(dev, lo, hi):
+        try:
+            set_device(dev)
+            part = [h[lo:hi] if (h.ndim == len(shape) and h.shape[0] == shape[0]) else h for h in host]
+            _run_single(name, part, ints, eps, None, host_out=[o[lo:hi] for o in outs])
+        except BaseException as exc:  # surfaced in the calling thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(d, lo, hi)) for d, (lo, hi) in zip(devs, bounds)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    if errors:
+        raise errors[0]
+    return tuple(outs)
+
+
+def _run_single(name, args, ints=(), eps=None, dtype=None, host_out=None):
     ins, outs, int_names, has_eps = OPS[name]
     assert len(args) == len(ins) and len(ints) == len(int_names)
     plan = _Plan(args, dtype)
@@ -171,10 +231,16 @@ def run(name, args, ints=(), eps=None, dtype=None):
         return tuple(results)
 
     host = []
-    for r in results:
-        h = r.to_host()  # synchronises the stream
+    for k, r in enumerate(results):
+        if host_out is not None and host_out[k].dtype == plan.dtype and host_out[k].flags.c_contiguous:
+            h = r.to_host(out=host_out[k])  # straight into the caller's slice
+        else:
+            h = r.to_host()  # synchronises the stream
+            if host_out is not None:
+                host_out[k][...] = h
+                h = host_out[k]
         r.free()
-        if plan.out_dtype != plan.dtype:
+        if plan.out_dtype != plan.dtype and host_out is None:
             h = h.astype(plan.out_dtype)
         host.append(h[()] if plan.all_scalar else h)
     for t in temps:

@@ -38,6 +38,36 @@ def set_device(dev):
     _tls.device = int(dev)
 
 
+def current_devices():
+    """The GPUs selected by an enclosing `multi_gpu()` block (None outside one)."""
+    return getattr(_tls, "devices", None)
+
+
+class multi_gpu:
+    """Context manager: inside it, thermo calls on NumPy inputs are sharded by grid point across
+    `devices` (default: all visible GPUs), one host thread per GPU, no collective of any kind::
+
+        with ekm_hip.multi_gpu():
+            rh = thermo.relative_humidity_from_specific_humidity(t, q, p)   # [137, 1800, 3600] fields
+    """
+
+    def __init__(self, devices=None):
+        self.devices = list(range(device_count())) if devices is None else [int(d) for d in devices]
+        n = device_count()
+        for d in self.devices:
+            if not 0 <= d < n:
+                raise _ffi.EkmError(f"device {d} does not exist ({n} visible)")
+
+    def __enter__(self):
+        self._prev = getattr(_tls, "devices", None)
+        _tls.devices = self.devices
+        return self
+
+    def __exit__(self, *exc):
+        _tls.devices = self._prev
+        return False
+
+
 def current_stream():
     return getattr(_tls, "stream", None)
 
@@ -205,8 +235,11 @@ class DeviceArray:
         _ffi.check(lib.ekm_stream_sync(self.device, current_stream()))
         return self
 
-    def to_host(self):
-        out = np.empty(self.shape, dtype=self.dtype)
+    def to_host(self, out=None):
+        if out is None:
+            out = np.empty(self.shape, dtype=self.dtype)
+        elif out.dtype != self.dtype or out.size != self.size or not out.flags.c_contiguous:
+            raise ValueError("to_host(out=...): need a C-contiguous array of the same dtype and size")
         lib = _ffi.lib()
         _ffi.check(lib.ekm_d2h(self.device, out.ctypes.data, self.ptr, out.nbytes, current_stream()))
         _ffi.check(lib.ekm_stream_sync(self.device, current_stream()))

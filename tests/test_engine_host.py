@@ -101,3 +101,12 @@ def test_signatures_match_the_reference():
     for name, sig in sigs.items():
         assert str(inspect.signature(getattr(thermo, name))) == sig, name
         assert str(inspect.signature(getattr(orc, name))) == sig, name
+
+
+@pytest.mark.parametrize("n0,k", [(137, 8), (137, 1), (721, 4), (8, 8), (9, 8), (3, 2)])
+def test_leading_axis_bounds(n0, k):
+    b = _engine.leading_axis_bounds(n0, k)
+    assert len(b) == k and b[0][0] == 0 and b[-1][1] == n0
+    assert all(hi == lo2 for (_, hi), (lo2, _) in zip(b, b[1:]))
+    sizes = [hi - lo for lo, hi in b]
+    assert max(sizes) - min(sizes) <= 1

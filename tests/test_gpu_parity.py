@@ -411,3 +411,23 @@ def test_full_size_properties(ek):
     back = ek.thermo.temperature_from_potential_temperature(outs[0], p)
     a, b = back.ravel().flat_slice(0, 1 << 22).to_host(), t.ravel().flat_slice(0, 1 << 22).to_host()
     assert rel_err(a, b).max() < 2e-6
+
+
+def test_multi_gpu_sharding_in_process(ek, orc, slab):
+    """ekm_hip.multi_gpu(): NumPy fields cut along the leading axis, one host thread per device (here the
+    same GPU three times -- the driver's multi-GPU bench covers real devices), results identical to a
+    single-device call and written straight into slices of one output array."""
+    t, q, p = (slab["f32"][k] for k in ("t", "q", "p"))  # [16, 16387]
+    single = ek.thermo.pipeline_full(t, q, p)
+    with ek.multi_gpu([0, 0, 0]):
+        multi = ek.thermo.pipeline_full(t, q, p)
+        lev = ek.thermo.potential_temperature(t, p[:, :1].copy())          # [16, 1] level vector: sliced per shard
+        sc = ek.thermo.dewpoint_from_specific_humidity(q, np.float32(85000.0))  # scalar: passed whole
+        few = ek.thermo.potential_temperature(t[:2], p[:2])                 # fewer rows than devices: single path
+    for a, b in zip(single, multi):
+        assert b.shape == t.shape and b.dtype == np.float32 and np.array_equal(a, b, equal_nan=True)
+    assert_parity(lev, orc.potential_temperature(t, p[:, :1]), "f32", "sharded level vector")
+    assert_parity(sc, orc.dewpoint_from_specific_humidity(q, np.float32(85000.0)), "f32", "sharded scalar p")
+    assert few.shape == (2, t.shape[1])
+    with pytest.raises(ek.EkmError):
+        ek.multi_gpu([0, 99])
