@@ -146,6 +146,9 @@ __global__ __launch_bounds__(kThreads) void geopotential_columns(const T* __rest
 #pragma unroll
   for (int j = 0; j < V; ++j) acc[j] = T(0);
   Vec phn = A[nfull] + B[nfull] * s;  // lower half level of the current layer
+#ifdef EKM_GEO_UNROLL
+#pragma unroll EKM_GEO_UNROLL
+#endif
   for (unsigned kk = nfull; kk-- > 0;) {
     const Vec ph = A[kk] + B[kk] * s;
     const Vec tk = get(t, kk), qk = get(q, kk);
