@@ -157,7 +157,11 @@ struct OpPipelineFull {
     y[2] = T(100.0) * e * m_rcp(es);                  // thermo.py:556
     y[3] = td;
     y[4] = the;
+#ifdef EKM_P5_NOWB  // diagnostic build: how long do the nine streams take with the wet-bulb arithmetic removed?
+    y[5] = the + P.pp;
+#else
     y[5] = t_on_ma_newton_ifs(the, P);                // thermo.py:1081-1159
+#endif
   }
 };
 

@@ -431,3 +431,44 @@ def test_multi_gpu_sharding_in_process(ek, orc, slab):
     assert few.shape == (2, t.shape[1])
     with pytest.raises(ek.EkmError):
         ek.multi_gpu([0, 99])
+
+
+def test_more_than_2_to_32_points(ek, orc):
+    """64-bit indexing: a field of 2^32 + 4099 points (17 GB per variable), checked at both ends and
+    across the 2^32 boundary; fields, a scalar operand and a level vector."""
+    import ctypes as C
+
+    from ekm_hip import _ffi
+
+    n = (1 << 32) + 4099
+    lib = _ffi.lib()
+    free, total = C.c_size_t(), C.c_size_t()
+    _ffi.check(lib.ekm_mem_info(0, C.byref(free), C.byref(total)))
+    if free.value < 5 * n * 4:
+        pytest.skip("needs 90 GB of HBM")
+    inner = 1 << 25
+    nlev = -(-n // inner)  # 129 levels, the last one ragged
+    t, q, p = (ek.DeviceArray.empty((n,), np.float32) for _ in range(3))
+    _ffi.check(lib.ekm_synth_fill_f32(0, None, t.ptr, q.ptr, p.ptr, 0, n, inner, nlev, 7))
+    th = ek.thermo.potential_temperature(t, p)
+    td = ek.thermo.dewpoint_from_specific_humidity(q, np.float32(90000.0))
+    pl = (101325.0 - 700.0 * np.arange(nlev)).astype(np.float32)
+    plev = ek.to_device(pl)
+    from ekm_hip._engine import _run_single  # level vector against a flat field: describe it explicitly
+    op = lambda d: C.byref(_ffi.Operand(d.ptr, _ffi.FIELD, 0, 0, 0))  # noqa: E731
+    thl = ek.DeviceArray.empty((n,), np.float32)
+    _ffi.check(lib.ekm_potential_temperature_f32(0, None, op(t), C.byref(_ffi.Operand(plev.ptr, _ffi.LEVEL_MAJOR, 0, nlev, inner)),
+                                                 thl.ptr, n))
+    ek.synchronize()
+    for lo in (0, (1 << 32) - 2048, n - 4099 - 1000, n - 4099):
+        hi = min(lo + 4099, n)
+        ht, hq, hp = (a.flat_slice(lo, hi).to_host() for a in (t, q, p))
+        assert_parity(th.flat_slice(lo, hi).to_host(), orc.potential_temperature(ht, hp), "f32", f"theta at {lo}")
+        assert_parity(td.flat_slice(lo, hi).to_host(), orc.dewpoint_from_specific_humidity(hq, np.float32(90000.0)), "f32",
+                      f"td scalar p at {lo}")
+        lev = (np.arange(lo, hi) // inner)
+        assert_parity(thl.flat_slice(lo, hi).to_host(), orc.potential_temperature(ht, pl[lev]), "f32",
+                      f"theta level vector at {lo}")
+    for a in (t, q, p, th, td, thl):
+        a.free()
+    ek.empty_cache()
