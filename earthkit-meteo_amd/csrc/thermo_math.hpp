@@ -80,6 +80,71 @@ EKM_HD float m_exp(float x) { return std::exp(x); }
 EKM_HD float m_log(float x) { return std::log(x); }
 EKM_HD float m_pow(float x, float y) { return std::pow(x, y); }
 #endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(EKM_F64_LIBM)
+// fp64 on gfx950: there is no fp64 transcendental unit and the device libm pays for correctly
+// rounded results (pow alone is ~200 instructions).  The bar here is 1e-6 relative, so: reciprocal =
+// v_rcp_f64 seed + two Newton steps (exact to rounding), exp2 = round-to-nearest split + degree-12
+// Taylor of e^(f ln2) + v_ldexp_f64 (<= 2e-16 relative), log2 = v_frexp + atanh series in
+// s = (m-1)/(m+1) to s^21 (<= 3e-16), pow = exp2(y*log2(x)).  inf / 0 / NaN behave as in libm.
+EKM_HD double m_rcp(double x) {
+  const double r0 = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r0, 1.0);
+  double r = __builtin_fma(r0, e, r0);
+  e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return __builtin_isfinite(r) ? r : r0;  // x = 0, inf, NaN: keep the hardware answer (inf, 0, NaN)
+}
+EKM_HD double m_div(double a, double b) { return a * m_rcp(b); }
+EKM_HD double m_exp2(double x) {
+  const double xc = __builtin_fmin(__builtin_fmax(x, -1100.0), 1100.0);
+  const double n = __builtin_rint(xc);
+  const double y = (xc - n) * 0.69314718055994530942;  // |y| <= 0.3466
+  double p = 1.0 / 479001600.0;                          // Taylor of e^y, degree 12
+  p = __builtin_fma(p, y, 1.0 / 39916800.0);
+  p = __builtin_fma(p, y, 1.0 / 3628800.0);
+  p = __builtin_fma(p, y, 1.0 / 362880.0);
+  p = __builtin_fma(p, y, 1.0 / 40320.0);
+  p = __builtin_fma(p, y, 1.0 / 5040.0);
+  p = __builtin_fma(p, y, 1.0 / 720.0);
+  p = __builtin_fma(p, y, 1.0 / 120.0);
+  p = __builtin_fma(p, y, 1.0 / 24.0);
+  p = __builtin_fma(p, y, 1.0 / 6.0);
+  p = __builtin_fma(p, y, 0.5);
+  p = __builtin_fma(p, y, 1.0);
+  p = __builtin_fma(p, y, 1.0);
+  const double r = __builtin_amdgcn_ldexp(p, (int)n);
+  return x != x ? x : r;
+}
+EKM_HD double m_log2(double x) {
+  int e = __builtin_amdgcn_frexp_exp(x);
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  if (m < 0.70710678118654752440) {
+    m *= 2.0;
+    e -= 1;
+  }
+  const double s = (m - 1.0) * m_rcp(m + 1.0);  // |s| <= 0.1716
+  const double z = s * s;
+  double p = 1.0 / 21.0;                           // atanh series: ln(m) = 2s(1 + z/3 + z^2/5 + ...)
+  p = __builtin_fma(p, z, 1.0 / 19.0);
+  p = __builtin_fma(p, z, 1.0 / 17.0);
+  p = __builtin_fma(p, z, 1.0 / 15.0);
+  p = __builtin_fma(p, z, 1.0 / 13.0);
+  p = __builtin_fma(p, z, 1.0 / 11.0);
+  p = __builtin_fma(p, z, 1.0 / 9.0);
+  p = __builtin_fma(p, z, 1.0 / 7.0);
+  p = __builtin_fma(p, z, 1.0 / 5.0);
+  p = __builtin_fma(p, z, 1.0 / 3.0);
+  p = __builtin_fma(p, z, 1.0);
+  double r = __builtin_fma(p * s, 2.0 * 1.44269504088896340736, (double)e);
+  if (x == 0.0) r = -__builtin_inf();
+  if (x == __builtin_inf()) r = x;
+  if (x < 0.0 || x != x) r = __builtin_nan("");
+  return r;
+}
+EKM_HD double m_exp(double x) { return m_exp2(x * 1.44269504088896340736); }
+EKM_HD double m_log(double x) { return m_log2(x) * 0.69314718055994530942; }
+EKM_HD double m_pow(double x, double y) { return m_exp2(y * m_log2(x)); }
+#else
 EKM_HD double m_rcp(double x) { return 1.0 / x; }
 EKM_HD double m_div(double a, double b) { return a / b; }
 EKM_HD double m_exp2(double x) { return exp2(x); }
@@ -87,6 +152,7 @@ EKM_HD double m_log2(double x) { return log2(x); }
 EKM_HD double m_exp(double x) { return exp(x); }
 EKM_HD double m_log(double x) { return log(x); }
 EKM_HD double m_pow(double x, double y) { return pow(x, y); }
+#endif
 
 template <class T>
 EKM_HD T m_sq(T x) {

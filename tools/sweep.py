@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--levels", type=int, default=137)
     ap.add_argument("--pmode", default="field")
     ap.add_argument("--out", default="")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--skew", default="0", help="comma list: byte offset added to the k-th array's base (k*skew)")
     a = ap.parse_args()
 
@@ -58,6 +59,7 @@ def main():
     base = next(iter(libs.values()))
     chk = lambda rc: rc >= 0 or sys.exit(f"error {rc}: {base.ekm_last_error().decode()}")  # noqa: E731
     dev, n = 0, a.levels * INNER
+    isz = 4 if a.dtype == "f32" else 8
 
     skews = [int(x) for x in a.skew.split(",")]
     maxskew = max(skews) * 10
@@ -67,12 +69,12 @@ def main():
         chk(base.ekm_malloc(dev, nbytes + maxskew, C.byref(p)))
         return p.value
 
-    bases = [dmalloc(4 * n) for _ in range(9)]
-    pl = dmalloc(4 * a.levels)
+    bases = [dmalloc(isz * n) for _ in range(9)]
+    pl = dmalloc(isz * a.levels)
     t, q, p = bases[:3]
     outs = bases[3:]
-    chk(base.ekm_synth_fill_f32(dev, None, t, q, p, 0, n, INNER, a.levels, 20260313))
-    chk(base.ekm_synth_levels_f32(dev, None, pl, a.levels))
+    chk(getattr(base, f'ekm_synth_fill_{a.dtype}')(dev, None, t, q, p, 0, n, INNER, a.levels, 20260313))
+    chk(getattr(base, f'ekm_synth_levels_{a.dtype}')(dev, None, pl, a.levels))
     ev0, ev1 = C.c_void_p(), C.c_void_p()
     chk(base.ekm_event_create(dev, C.byref(ev0)))
     chk(base.ekm_event_create(dev, C.byref(ev1)))
@@ -89,7 +91,7 @@ def main():
             lib = libs[ln]
             entry, which, ints, nout, bpp = W[w]
             chk(lib.ekm_set_tuning(b, u))
-            fn = getattr(lib, f"ekm_{entry}_f32")
+            fn = getattr(lib, f"ekm_{entry}_{a.dtype}")
             sops = {"t": F(t, 0, 0, 0, 0), "q": F(q + sk, 0, 0, 0, 0),
                     "p": F(p + 2 * sk, 0, 0, 0, 0) if a.pmode == "field" else ops["p"]}
             cargs = [dev, None] + [C.byref(sops[k]) for k in which] + list(ints) + \
@@ -107,7 +109,7 @@ def main():
     rows = []
     for c in configs:
         ln, b, u, w, sk = c
-        bpp = W[w][4] - (4 if a.pmode == "level" and "p" in W[w][1] else 0)
+        bpp = (W[w][4] - (4 if a.pmode == "level" and "p" in W[w][1] else 0)) * isz // 4
         med, mn = statistics.median(times[c]), min(times[c])
         rows.append(dict(lib=ln, tiles=b, unroll=u, workload=w, skew=sk, med_ms=round(med, 4), min_ms=round(mn, 4),
                          gbs_med=round(bpp * n / med / 1e6, 1), frac=round(bpp * n / med / 1e6 / 8000, 4)))
