@@ -214,42 +214,42 @@ EKM_HD void es_slope_ice(T t, T& es, T& des) {
 
 // Mixed phase (es_comp.py:141-166).  The reference gathers three masks; per point that
 // is: ice at t <= TI, water at t >= T0, alpha-blend in between.  NaN fails both tests and
-// lands in the blend, giving NaN.  The water (ice) formula is evaluated only when some
-// lane of the wave is above TI (below T0).
+// lands in the blend, giving NaN.  A wave whose lanes are all at or below TI (all at or
+// above T0) takes the one-phase formula alone: atmospheric fields are coherent along a level.
 template <class T>
 EKM_HD T es_mixed(T t) {
   const bool ice = t <= T(k::TI), wat = t >= T(k::T0);
-  T ew = T(0), ei = T(0);
-  if (EKM_ANY(!ice)) ew = es_water(t);
-  if (EKM_ANY(!wat)) ei = es_ice(t);
-  T es = ice ? ei : ew;
-  if (EKM_ANY(!(ice || wat))) {  // some lane sits in the blend range (or is NaN)
-    const T a = m_sq((t - T(k::TI)) * T(1.0 / (k::T0 - k::TI)));
-    const T mid = a * (ew - ei) + ei;  // = a*ew + (1-a)*ei
-    es = (ice || wat) ? es : mid;
-  }
-  return es;
+  if (!EKM_ANY(!ice)) return es_ice(t);    // the whole wave is at or below TI: one rcp + one exp2
+  if (!EKM_ANY(!wat)) return es_water(t);  // the whole wave is at or above T0
+  const T ew = es_water(t), ei = es_ice(t);
+  const T a = m_sq((t - T(k::TI)) * T(1.0 / (k::T0 - k::TI)));
+  const T mid = a * (ew - ei) + ei;  // = a*ew + (1-a)*ei
+  return ice ? ei : (wat ? ew : mid);
 }
 
 // es and slope of the mixed phase together (es_comp.py:177-200)
 template <class T>
 EKM_HD void es_slope_mixed(T t, T& es, T& des) {
   const bool ice = t <= T(k::TI), wat = t >= T(k::T0);
-  T ew = T(0), dw = T(0), ei = T(0), di = T(0);
-  if (EKM_ANY(!ice)) es_slope_water(t, ew, dw);
-  if (EKM_ANY(!wat)) es_slope_ice(t, ei, di);
-  es = ice ? ei : ew;
-  des = ice ? di : dw;
-  if (EKM_ANY(!(ice || wat))) {  // some lane sits in the blend range (or is NaN)
-    const T x = t - T(k::TI);
-    const T a = m_sq(x * T(1.0 / (k::T0 - k::TI)));
-    const T da = T(k::dalpha_c) * x;
-    const T dif = ew - ei;
-    const T mid = a * dif + ei;                      // a*ew + (1-a)*ei
-    const T dmid = da * dif + (a * (dw - di) + di);  // da*ew + a*dw - da*ei + (1-a)*di
-    es = (ice || wat) ? es : mid;
-    des = (ice || wat) ? des : dmid;
+  if (!EKM_ANY(!ice)) {
+    es_slope_ice(t, es, des);
+    return;
   }
+  if (!EKM_ANY(!wat)) {
+    es_slope_water(t, es, des);
+    return;
+  }
+  T ew, dw, ei, di;
+  es_slope_water(t, ew, dw);
+  es_slope_ice(t, ei, di);
+  const T x = t - T(k::TI);
+  const T a = m_sq(x * T(1.0 / (k::T0 - k::TI)));
+  const T da = T(k::dalpha_c) * x;
+  const T dif = ew - ei;
+  const T mid = a * dif + ei;                      // a*ew + (1-a)*ei
+  const T dmid = da * dif + (a * (dw - di) + di);  // da*ew + a*dw - da*ei + (1-a)*di
+  es = ice ? ei : (wat ? ew : mid);
+  des = ice ? di : (wat ? dw : dmid);
 }
 
 template <int PHASE, class T>
