@@ -443,8 +443,28 @@ EKM_HD float wbpt_direct(float e) {
 }
 
 // Moist-adiabat inversion by 12 fixed halvings (thermo.py:1055-1079)
+// IFS variant of the 12 halvings with the loop-invariant (p0/p)^kappa hoisted and the two
+// divisions of G_sat = -K0*qs/t merged into one reciprocal (same residual, thermo.py:1075,1177-1182).
+template <class T>
+EKM_HD T t_on_ma_bisect_ifs(T e, T p) {
+  const T thf = m_exp2(T(-k::kappa) * m_log2(p * T(1.0 / k::p0)));
+  T t = T(k::T0 - 20);
+  T dt = T(120.0);
+#pragma unroll 1
+  for (int it = 0; it < 12; ++it) {
+    const T es = es_mixed(t);
+    T v = p + T(k::eps - 1) * es;
+    if ((p - es) < T(k::eps_default)) v = nan_v<T>();
+    const T g = T(-k::K0_ifs * k::eps * k::LOG2E) * es * m_rcp(v * t);  // log2 of exp(-K0*qs/t)
+    dt *= T(0.5);
+    t += m_sign(e * m_exp2(g) - t * thf) * dt;
+  }
+  return t;
+}
+
 template <int METHOD, class T>
 EKM_HD T t_on_ma_bisect(T e, T p) {
+  if (METHOD == EPT_IFS) return t_on_ma_bisect_ifs(e, p);
   T t = T(k::T0 - 20);
   T dt = T(120.0);
 #pragma unroll 1
