@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <thread>
+#include <vector>
 
 #include "../../include/ekm_thermo.h"
 #include "thermo_math.hpp"
@@ -226,6 +228,28 @@ int ekm_host_alloc(size_t bytes, void** out) {
   int rc = probe();
   if (rc != EKM_OK) return rc;
   EKM_HIP(hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
+  return EKM_OK;
+}
+
+int ekm_host_prefault(void* ptr, size_t bytes, int nthreads) {
+  // Touch one byte per 4-KiB page of a freshly allocated host buffer so that the pages exist before a
+  // device-to-host copy lands in them (first-touch faults otherwise throttle the copy 56 -> 16 GB/s).
+  if (!ptr || bytes == 0) return EKM_OK;
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 16) nthreads = 16;
+  volatile char* base = static_cast<volatile char*>(ptr);
+  auto work = [base, bytes](size_t lo, size_t hi) {
+    for (size_t off = lo; off < hi; off += 4096) base[off] = 0;
+    if (hi == bytes) base[bytes - 1] = 0;
+  };
+  const size_t pages = (bytes + 4095) / 4096, per = (pages + nthreads - 1) / nthreads * 4096;
+  std::vector<std::thread> pool;
+  for (int i = 1; i < nthreads; ++i) {
+    const size_t lo = (size_t)i * per, hi = lo + per < bytes ? lo + per : bytes;
+    if (lo < bytes) pool.emplace_back(work, lo, hi);
+  }
+  work(0, per < bytes ? per : bytes);
+  for (auto& th : pool) th.join();
   return EKM_OK;
 }
 

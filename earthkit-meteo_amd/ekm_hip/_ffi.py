@@ -54,6 +54,7 @@ def _signatures():
         "ekm_mem_info": ([i, C.POINTER(sz), C.POINTER(sz)], i),
         "ekm_malloc": ([i, sz, pvp], i), "ekm_free": ([i, vp], i),
         "ekm_host_alloc": ([sz, pvp], i), "ekm_host_free": ([vp], i),
+        "ekm_host_prefault": ([vp, sz, i], i),
         "ekm_h2d": ([i, vp, vp, sz, vp], i), "ekm_d2h": ([i, vp, vp, sz, vp], i),
         "ekm_d2d": ([i, vp, vp, sz, vp], i), "ekm_memset": ([i, vp, i, sz, vp], i),
         "ekm_sync": ([i], i),

@@ -175,6 +175,7 @@ EKM_API int ekm_malloc(int dev, size_t bytes, void** out);
 EKM_API int ekm_free(int dev, void* ptr);
 EKM_API int ekm_host_alloc(size_t bytes, void** out);  /* pinned host memory for fast transfers */
 EKM_API int ekm_host_free(void* ptr);
+EKM_API int ekm_host_prefault(void* ptr, size_t bytes, int nthreads); /* touch every page of a fresh host buffer */
 EKM_API int ekm_h2d(int dev, void* dst, const void* src, size_t bytes, void* stream);
 EKM_API int ekm_d2h(int dev, void* dst, const void* src, size_t bytes, void* stream);
 EKM_API int ekm_d2d(int dev, void* dst, const void* src, size_t bytes, void* stream);
