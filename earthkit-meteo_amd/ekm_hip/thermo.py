@@ -295,3 +295,10 @@ def pipeline_full(t, q, p):
     ept_from_specific_humidity(method="ifs") and
     wet_bulb_temperature_from_specific_humidity(ept_method="ifs", t_method="newton") in a single pass."""
     return _engine.run("pipeline_full", (t, q, p))
+
+
+# `earthkit.meteo.thermo.array.<name>` is how the reference (and its tests) reach the array-level
+# functions (thermo/__init__.py:19, thermo/array/__init__.py:14): same module here.
+import sys as _sys  # noqa: E402
+
+array = _sys.modules[__name__]

@@ -472,3 +472,70 @@ def test_more_than_2_to_32_points(ek, orc):
     for a in (t, q, p, th, td, thl):
         a.free()
     ek.empty_cache()
+
+
+def test_reference_csv_fixtures_through_the_product(ek):
+    """The checks the reference's own test module makes against its tests/data/*.csv, with its tolerances
+    (default allclose; rtol=1e-3 for the wet-bulb files), made through `thermo.array.<name>` on the GPU."""
+    from _golden import ref_csv
+
+    c = ref_csv()
+    T = ek.thermo.array
+    t, td, q, p = (c[f"t_hum_p_data.{k}"] for k in ("t", "td", "q", "p"))
+    for ph in ("mixed", "water", "ice"):
+        assert np.allclose(T.saturation_vapour_pressure(c["sat_vp.t"], phase=ph), c[f"sat_vp.{ph}"])
+        assert np.allclose(T.saturation_vapour_pressure_slope(c["sat_vp_slope.t"], phase=ph), c[f"sat_vp_slope.{ph}"])
+        assert np.allclose(T.saturation_mixing_ratio(c["sat_mr.t"], c["sat_mr.p"], phase=ph), c[f"sat_mr.{ph}"])
+        assert np.allclose(T.saturation_specific_humidity(c["sat_q.t"], c["sat_q.p"], phase=ph), c[f"sat_q.{ph}"])
+        assert np.allclose(T.saturation_mixing_ratio_slope(c["sat_mr_slope.t"], c["sat_mr_slope.p"], phase=ph),
+                           c[f"sat_mr_slope.{ph}"])
+        assert np.allclose(T.saturation_specific_humidity_slope(c["sat_q_slope.t"], c["sat_q_slope.p"], phase=ph),
+                           c[f"sat_q_slope.{ph}"])
+    assert np.allclose(T.temperature_from_saturation_vapour_pressure(c["sat_vp.water"]), c["sat_vp.t"])
+    for m in ("ifs", "bolton35", "bolton39"):
+        assert np.allclose(T.ept_from_dewpoint(t, td, p, method=m), c[f"eqpt.{m}_td"])
+        assert np.allclose(T.ept_from_specific_humidity(t, q, p, method=m), c[f"eqpt.{m}_q"])
+        assert np.allclose(T.saturation_ept(t, p, method=m), c[f"seqpt.{m}"])
+        for tm in ("bisect", "newton"):
+            got = T.temperature_on_moist_adiabat(c["t_on_most_adiabat.ept"], c["t_on_most_adiabat.p"], ept_method=m,
+                                                 t_method=tm)
+            assert np.allclose(got, c[f"t_on_most_adiabat.{m}_{tm}"], rtol=1e-3 if tm == "bisect" else 1e-5,
+                               equal_nan=True)
+            for hum, arg in (("td", td), ("q", q)):
+                f = T.wet_bulb_temperature_from_dewpoint if hum == "td" else T.wet_bulb_temperature_from_specific_humidity
+                got = f(t, arg, p, ept_method=m, t_method=tm)
+                want = c[f"t_wet.{m}_{tm}_{hum}"]
+                # saturated low-pressure rows: bisection turns NaN on a rounding-level sign flip (DESIGN.md)
+                ok = np.isfinite(got) & np.isfinite(want)
+                assert (np.isfinite(got) != np.isfinite(want)).mean() < 0.03
+                assert np.allclose(got[ok], want[ok], rtol=1e-3, atol=0)
+        for tm in ("direct", "bisect", "newton"):
+            for hum, arg in (("td", td), ("q", q)):
+                f = (T.wet_bulb_potential_temperature_from_dewpoint if hum == "td"
+                     else T.wet_bulb_potential_temperature_from_specific_humidity)
+                got = f(t, arg, p, ept_method=m, t_method=tm)
+                want = c[f"t_wetpt.{m}_{tm}_{hum}"]
+                ok = np.isfinite(got) & np.isfinite(want)
+                assert (np.isfinite(got) != np.isfinite(want)).mean() < 0.03
+                assert np.allclose(got[ok], want[ok], rtol=1e-3, atol=0)
+
+
+def test_device_array_api(ek):
+    a = np.arange(24, dtype=np.float32).reshape(2, 3, 4)
+    d = ek.to_device(a)
+    assert d.shape == (2, 3, 4) and d.size == 24 and d.ndim == 3 and len(d) == 2 and d.nbytes == 96
+    assert np.array_equal(np.asarray(d), a) and np.array_equal(d.reshape(6, 4).to_host(), a.reshape(6, 4))
+    assert np.array_equal(d.reshape(-1, 8).to_host(), a.reshape(-1, 8)) and np.array_equal(d.ravel().to_host(), a.ravel())
+    assert np.array_equal(d.flat_slice(5, 11).to_host(), a.ravel()[5:11])
+    with pytest.raises(ValueError):
+        d.reshape(5, 5)
+    with pytest.raises(IndexError):
+        d.flat_slice(3, 99)
+    with pytest.raises(TypeError):
+        ek.DeviceArray.empty((3,), np.int32)
+    out = np.empty((2, 3, 4), np.float32)
+    assert d.to_host(out=out) is out and np.array_equal(out, a)
+    h16 = ek.thermo.celsius_to_kelvin(np.array([1.0, 2.0], dtype=np.float16))   # computed in fp32, returned as fp16
+    assert h16.dtype == np.float16 and np.allclose(h16, [274.2, 275.2], rtol=2e-3)
+    d.free()
+    ek.empty_cache()
