@@ -26,7 +26,10 @@
 
 namespace ekm {
 
-constexpr int kThreads = 256;
+#ifndef EKM_THREADS
+#define EKM_THREADS 256
+#endif
+constexpr int kThreads = EKM_THREADS;
 #ifndef EKM_WAVES_PER_EU
 #define EKM_WAVES_PER_EU 1
 #endif
