@@ -359,11 +359,19 @@ def check_parity(args, t, q, p, plev, outs, n_local, first, nlev, np_dtype, hyb=
         want = vo.geopotential_on_hybrid_levels(col(t), col(q), hyb["zsh"][c0:c0 + nc], hyb["Ah"].astype(np_dtype),
                                                 hyb["Bh"].astype(np_dtype), hyb["sph"][c0:c0 + nc])
         got = col(outs[0]).astype(np.float64)
+        # bar: the reference's own fp32 tolerance for this chain (atol 10 m2/s2, rtol 1e-6), against the oracle
+        # evaluated in fp64 on the same inputs (the fp32 reference is itself 2 % off in alpha for thin layers)
+        want = vo.geopotential_on_hybrid_levels(*(np.asarray(x, np.float64) for x in (
+            col(t), col(q), hyb["zsh"][c0:c0 + nc], hyb["Ah"], hyb["Bh"], hyb["sph"][c0:c0 + nc])))
         with np.errstate(all="ignore"):
-            r = np.abs(got - want) / np.maximum(np.abs(want), 100.0)  # relative, with a 100 m2/s2 floor near the surface
+            aerr = np.abs(got - want)
+            r = aerr / np.abs(want)
         nanmm = int((np.isnan(got) != np.isnan(want)).sum())
-        return {"points": int(got.size), "max_rel_err": float(np.nanmax(r)), "nan_mismatch": nanmm, "tolerance": tol,
-                "excluded_regime_boundary_points": 0, "ok": bool(nanmm == 0 and np.nanmax(r) <= tol)}
+        ok = bool(nanmm == 0 and np.all(aerr <= 10.0 + 1e-6 * np.abs(want))) if args.dtype == "f32" else bool(
+            nanmm == 0 and np.nanmax(r) <= tol)
+        return {"points": int(got.size), "max_rel_err": float(np.nanmax(r)), "max_abs_err": float(np.nanmax(aerr)),
+                "nan_mismatch": nanmm, "tolerance": "atol 10 m2/s2 + rtol 1e-6 (reference's fp32 bar)" if args.dtype == "f32" else tol,
+                "excluded_regime_boundary_points": 0, "ok": ok}
     wins = []
     lo_lev = 0
     if args.pmode == "hybrid" and args.workload != "hybrid_levels":

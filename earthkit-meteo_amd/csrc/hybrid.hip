@@ -19,6 +19,33 @@
 
 namespace ekm {
 
+// delta = log(p_lo/p_hi) and alpha = 1 - p_hi/(p_lo - p_hi)*delta of one layer (vertical.py:679, 690).
+// alpha cancels to ~1e-2 of its terms, so the logarithm must be relatively accurate for ratios near 1:
+// fp32 uses log(r) = 2 atanh(s), s = (p_lo - p_hi)/(p_lo + p_hi) <= 0.25, as an odd series to s^15
+// (<= 3e-8 relative, no cancellation, one v_rcp_f32 + 9 FMAs instead of libm log + two IEEE divisions);
+// fp64 uses the device libm.
+__device__ __forceinline__ void layer_delta_alpha(float p_hi, float p_lo, float& d, float& a) {
+  const float dif = p_lo - p_hi;
+  const float s = dif * __builtin_amdgcn_rcpf(p_lo + p_hi);
+  const float z = s * s;
+  float q = 1.0f / 15.0f;
+  q = __builtin_fmaf(q, z, 1.0f / 13.0f);
+  q = __builtin_fmaf(q, z, 1.0f / 11.0f);
+  q = __builtin_fmaf(q, z, 1.0f / 9.0f);
+  q = __builtin_fmaf(q, z, 1.0f / 7.0f);
+  q = __builtin_fmaf(q, z, 1.0f / 5.0f);
+  q = __builtin_fmaf(q, z, 1.0f / 3.0f);
+  q = __builtin_fmaf(q, z, 1.0f);
+  d = 2.0f * s * q;
+  if (!(s < 0.25f)) d = log(p_lo / p_hi);  // thick layers (and inf / NaN / negative pressure): libm
+  a = 1.0f - p_hi * __builtin_amdgcn_rcpf(dif) * d;
+}
+
+__device__ __forceinline__ void layer_delta_alpha(double p_hi, double p_lo, double& d, double& a) {
+  d = log(p_lo / p_hi);
+  a = 1.0 - p_hi / (p_lo - p_hi) * d;
+}
+
 template <class T>
 __global__ __launch_bounds__(kThreads) void hybrid_levels(const T* __restrict__ A, const T* __restrict__ B,
                                                          const T* __restrict__ sp, unsigned long long npts,
@@ -67,8 +94,10 @@ __global__ __launch_bounds__(kThreads) void hybrid_levels(const T* __restrict__ 
             d[j] = log(phn[j] / T(0.1));
             a[j] = alpha_top;
           } else {
-            d[j] = log(phn[j] / ph[j]);
-            a[j] = T(1.0) - ph[j] / (phn[j] - ph[j]) * d[j];
+            T dj, aj;
+            layer_delta_alpha(ph[j], phn[j], dj, aj);
+            d[j] = dj;
+            a[j] = aj;
           }
         }
         if (delta) put(delta, rf, d);
@@ -160,8 +189,7 @@ __global__ __launch_bounds__(kThreads) void geopotential_columns(const T* __rest
         d = log(phn[j] / T(0.1));
         a = alpha_top;
       } else {
-        d = log(phn[j] / ph[j]);
-        a = T(1.0) - ph[j] / (phn[j] - ph[j]) * d;
+        layer_delta_alpha(ph[j], phn[j], d, a);
       }
       const T rt = (T(k::Rd) + T(k::Rv - k::Rd) * qk[j]) * tk[j];  // thermo.py:1706, vertical.py:800-801
       const T dphi = acc[j] + rt * a;

@@ -116,9 +116,12 @@ from test_vertical_oracle import CHAIN, chain_args, chain_calls  # noqa: E402
 
 @pytest.mark.parametrize("c", CHAIN, ids=[c["id"] for c in CHAIN])
 def test_geopotential_chain_golden(ek, c):
-    """Fused column scan (t, q, sp -> thickness / geopotential / heights) vs the reference's outputs:
-    fp64 1e-6 relative; fp32 1e-4 relative against the reference's fp32 result (+ 0.01 m / m2s-2
-    absolute for the near-surface values that cancel against the surface terms)."""
+    """Fused column scan (t, q, sp -> thickness / geopotential / heights) vs the reference's outputs.
+    fp64: 1e-6 relative.  fp32: the reference's own fp32 tolerance for this chain (atol 10 m2/s2 resp.
+    10/g m, rtol 1e-6; tests/vertical/test_array_vertical.py:430-431 there) against its fp32 result --
+    alpha = 1 - x*log(r) of a thin layer cancels to 1e-3 of its terms, and the reference's fp32 evaluation
+    of it is itself 2 % off there -- AND within 2e-4 relative (+0.05 absolute) of the reference's fp64
+    result, which the kernel's cancellation-free series tracks more closely than the fp32 reference does."""
     args = chain_args(c)
     for k, v in chain_calls(ek.vertical, *args).items():
         w = G[f"{c['id']}.{k}"]
@@ -126,7 +129,10 @@ def test_geopotential_chain_golden(ek, c):
         if c["dtype"] == "f64":
             assert np.allclose(v, w, rtol=1e-6, atol=1e-9), (c["id"], k, np.abs(v - w).max())
         else:
-            assert np.allclose(v, w, rtol=1e-4, atol=1e-2), (c["id"], k, np.abs(v - w).max())
+            atol = 10.0 if k in ("thickness", "geopotential") else 10.0 / 9.80665
+            assert np.allclose(v, w, rtol=1e-6, atol=atol), (c["id"], k, np.abs(v - w).max())
+            w64 = G[f"{c['id'].replace('.f32.', '.f64.')}.{k}"]
+            assert np.allclose(v, w64, rtol=2e-4, atol=0.05), (c["id"], k, np.abs(v - w64).max())
 
 
 def test_geopotential_chain_fixtures_and_device(ek):
@@ -149,6 +155,6 @@ def test_geopotential_chain_fixtures_and_device(ek):
     out = ek.vertical.geopotential_on_hybrid_levels(ek.to_device(t), ek.to_device(q), ek.to_device(zs), A, B,
                                                     ek.to_device(sp))
     assert isinstance(out, ek.DeviceArray) and out.shape == t.shape
-    assert np.allclose(out.to_host(), vo.geopotential_on_hybrid_levels(t, q, zs, A, B, sp), rtol=1e-4, atol=1e-2)
+    assert np.allclose(out.to_host(), vo.geopotential_on_hybrid_levels(t, q, zs, A, B, sp), rtol=1e-6, atol=10.0)
     with pytest.raises(ValueError, match="h_reference"):
         ek.vertical.height_on_hybrid_levels(t, q, zs, A, B, sp, h_reference="moon")
