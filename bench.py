@@ -200,6 +200,9 @@ def main():
     else:
         from ekm_hip.device import shard_bounds
 
+        if dist.world > 1 and (args.pmode != "field" or args.workload in ("hybrid_levels", "geopotential")):
+            sys.exit("--scaling strong cuts the flat grid-point range and needs --pmode field; the level / hybrid "
+                     "pressure modes and the column workloads run one whole field per GPU (--scaling weak)")
         lo, hi = shard_bounds(n_field, dist.world)[dist.rank]
         first, n_local = lo, hi - lo
         n_total = n_field

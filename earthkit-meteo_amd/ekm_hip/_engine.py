@@ -202,7 +202,9 @@ def _run_sharded(name, args, ints, eps, devs):
         try:
             set_device(dev)
             set_stream(_shard_stream(dev, lo))  # own stream: shards on one GPU overlap upload / kernel / download
-            part = [h[lo:hi] if (h.ndim == len(shape) and h.shape[0] == shape[0]) else h for h in host]
+            # operands that span the leading axis get the matching slice; everything else is passed as
+            # the caller gave it (a Python scalar must stay a weak scalar for the dtype promotion)
+            part = [h[lo:hi] if (h.ndim == len(shape) and h.shape[0] == shape[0]) else a for h, a in zip(host, args)]
             _run_single(name, part, ints, eps, None, host_out=[o[lo:hi] for o in outs])
         except BaseException as exc:  # surfaced in the calling thread
             errors.append(exc)

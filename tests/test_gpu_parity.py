@@ -424,6 +424,8 @@ def test_multi_gpu_sharding_in_process(ek, orc, slab):
         lev = ek.thermo.potential_temperature(t, p[:, :1].copy())          # [16, 1] level vector: sliced per shard
         sc = ek.thermo.dewpoint_from_specific_humidity(q, np.float32(85000.0))  # scalar: passed whole
         few = ek.thermo.potential_temperature(t[:2], p[:2])                 # fewer rows than devices: single path
+        weak = ek.thermo.potential_temperature(t, 85000.0)                  # Python scalar stays weak: fp32 result
+    assert weak.dtype == np.float32 and weak.shape == t.shape
     for a, b in zip(single, multi):
         assert b.shape == t.shape and b.dtype == np.float32 and np.array_equal(a, b, equal_nan=True)
     assert_parity(lev, orc.potential_temperature(t, p[:, :1]), "f32", "sharded level vector")
