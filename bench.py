@@ -56,8 +56,8 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="full", choices=sorted(WORKLOADS))
     ap.add_argument("--pmode", default="field", choices=["field", "level", "hybrid"],
                     help="pressure as a full field, as the 137-level vector staged in LDS, or formed in the kernel "
