@@ -541,3 +541,17 @@ def test_device_array_api(ek):
     assert h16.dtype == np.float16 and np.allclose(h16, [274.2, 275.2], rtol=2e-3)
     d.free()
     ek.empty_cache()
+
+
+def test_entry_points_are_graph_capturable():
+    """tests/native/graph_capture.cpp: two thermo launches recorded into a hipGraph, replayed three times on
+    new inputs, bit-identical to direct launches (the C ABI's 'no allocation, no copy, no sync' convention)."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "graph_capture")
+    if not os.path.exists(exe):
+        pytest.skip("tests/_build/graph_capture not built (make -C earthkit-meteo_amd)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical" in r.stdout
