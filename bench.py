@@ -281,7 +281,7 @@ def main():
         ints = {"wetbulb": (0, 1), "wetbulb_bisect": (0, 0), "svp": (0,), "ept": (0,)}.get(args.workload, ())
         cargs = [dev, None] + [C.byref(o) for o in operands] + list(ints) + [o.ptr for o in outs] + [n_local]
         if args.workload == "geopotential":
-            zs_host = np.maximum(0.0, (101325.0 - hyb["sph"].astype(np.float64)) * 8.4).astype(np_dtype)  # ~ g*z of the orography
+            zs_host = np.maximum(0.0, (101325.0 - hyb["sph"].astype(np.float64)) / 1.2).astype(np_dtype)  # g*z ~ dp / rho
             hyb["zs"], hyb["zsh"] = DeviceArray.from_host(zs_host, dev), zs_host
             cargs = [dev, None, hyb["A"].ptr, hyb["B"].ptr, hyb["sp"].ptr, hyb["zs"].ptr, t.ptr, q.ptr, INNER, nlev, 1,
                      float(np.log(2)), 1, outs[0].ptr]

@@ -158,3 +158,17 @@ def test_geopotential_chain_fixtures_and_device(ek):
     assert np.allclose(out.to_host(), vo.geopotential_on_hybrid_levels(t, q, zs, A, B, sp), rtol=1e-6, atol=10.0)
     with pytest.raises(ValueError, match="h_reference"):
         ek.vertical.height_on_hybrid_levels(t, q, zs, A, B, sp, h_reference="moon")
+
+
+def test_example_model_level_postprocessing(ek):
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples",
+                        "model_level_postprocessing.py")
+    spec = importlib.util.spec_from_file_location("example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rh, h = mod.main(nlat=37, nlon=72)
+    assert rh.shape == (137, 37, 72) and np.isfinite(rh[40:]).all() and np.isfinite(h).all()
+    assert (np.diff(h, axis=0) < 0).all()  # height decreases from the model top to the surface
