@@ -333,6 +333,9 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles(args, n_local),
                     "kernel": entry, "bytes_per_point": bpp, "points_per_launch": n_local,
                     "kernel_ms": round(kernel_ms, 4)}
+            if args.workload.startswith("wetbulb"):
+                # honest label: these kernels are limited by VALU issue (transcendentals at 1/4 rate), not by HBM
+                roof["limiter"] = "valu-issue (DESIGN.md section 4); frac is still quoted against the HBM roofline"
         line = {
             "metric": "grid-points/sec for fused thermo pipeline; achieved HBM GB/s vs peak",
             "value": value, "unit": "grid-points/s", "n_gpus": dist.world, "steps": args.steps,
