@@ -14,6 +14,7 @@ from .device import (  # noqa: F401
     DeviceArray,
     current_device,
     device_count,
+    device_info,
     empty_cache,
     multi_gpu,
     set_device,

@@ -22,6 +22,18 @@ def device_count():
     return _ffi.check(_ffi.lib().ekm_device_count())
 
 
+def device_info(dev=None):
+    """Name, compute units and memory of a GPU as the library sees it."""
+    lib = _ffi.lib()
+    dev = current_device() if dev is None else dev
+    buf = C.create_string_buffer(256)
+    _ffi.check(lib.ekm_device_name(dev, buf, 256))
+    free, total = C.c_size_t(), C.c_size_t()
+    _ffi.check(lib.ekm_mem_info(dev, C.byref(free), C.byref(total)))
+    return {"device": dev, "name": buf.value.decode(), "compute_units": _ffi.check(lib.ekm_device_cus(dev)),
+            "hbm_free_bytes": free.value, "hbm_total_bytes": total.value, "library": lib.ekm_version().decode()}
+
+
 def current_device():
     dev = getattr(_tls, "device", None)
     if dev is None:

@@ -555,3 +555,8 @@ def test_entry_points_are_graph_capturable():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "identical" in r.stdout
+
+
+def test_device_info(ek):
+    info = ek.device_info(0)
+    assert info["compute_units"] == 256 and "gfx950" in info["name"] and info["hbm_total_bytes"] > 200e9
