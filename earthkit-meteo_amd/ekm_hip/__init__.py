@@ -27,3 +27,4 @@ from .device import (  # noqa: F401
 
 __version__ = "0.1.0"
 from .vertical import HybridPressure  # noqa: F401,E402
+from .dlpack import from_dlpack  # noqa: F401,E402

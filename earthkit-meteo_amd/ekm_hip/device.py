@@ -261,6 +261,17 @@ class DeviceArray:
         a = self.to_host()
         return a if dtype is None else a.astype(dtype, copy=False)
 
+    # ---- DLPack (zero-copy interop with other ROCm array libraries) ----
+    def __dlpack__(self, stream=None):
+        from .dlpack import to_dlpack
+
+        lib = _ffi.lib()
+        _ffi.check(lib.ekm_stream_sync(self.device, current_stream()))  # the consumer may use any stream
+        return to_dlpack(self)
+
+    def __dlpack_device__(self):
+        return (10, self.device)  # kDLROCM
+
     # ---- views (no data movement) ----
     def reshape(self, *shape):
         shape = shape[0] if len(shape) == 1 and not np.isscalar(shape[0]) else shape

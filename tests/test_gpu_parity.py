@@ -560,3 +560,33 @@ def test_entry_points_are_graph_capturable():
 def test_device_info(ek):
     info = ek.device_info(0)
     assert info["compute_units"] == 256 and "gfx950" in info["name"] and info["hbm_total_bytes"] > 200e9
+
+
+def test_dlpack_round_trip(ek):
+    """DeviceArray -> DLPack capsule (kDLROCM) -> DeviceArray: same memory, no copy; the exporter stays
+    alive until the consumer lets go; an unconsumed capsule releases its tensor when it dies."""
+    import gc
+
+    from ekm_hip import dlpack
+
+    a = ek.to_device(np.arange(24, dtype=np.float32).reshape(2, 3, 4))
+    assert a.__dlpack_device__() == (10, 0)
+    b = ek.from_dlpack(a)
+    assert b.ptr == a.ptr and b.shape == (2, 3, 4) and b.dtype == np.float32 and b.device == 0
+    assert len(dlpack._exports) == 1
+    th = ek.thermo.celsius_to_kelvin(b)              # kernels run on the borrowed memory
+    assert np.allclose(th.to_host(), np.arange(24).reshape(2, 3, 4) + 273.16)
+    ptr = a.ptr
+    del a                                             # the export keeps the allocation alive
+    gc.collect()
+    assert np.array_equal(b.to_host().ravel(), np.arange(24, dtype=np.float32)) and b.ptr == ptr
+    b.free()
+    assert len(dlpack._exports) == 0
+    c = ek.to_device(np.ones(5, np.float64))
+    cap = c.__dlpack__()
+    assert len(dlpack._exports) == 1
+    del cap
+    gc.collect()
+    assert len(dlpack._exports) == 0                  # never consumed: released by the capsule destructor
+    with pytest.raises(TypeError):
+        ek.from_dlpack(object())
