@@ -43,3 +43,21 @@ def test_shards_of_a_field_cover_it_exactly():
         b = shard_bounds(n3, world)
         assert sum(hi - lo for lo, hi in b) == n3
         assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 16 * world
+
+
+def test_bench_json_contract_single_rank():
+    """Every key the driver's bench contract names is present (dry run: no GPU, value null)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    meta = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == meta["metric"]
