@@ -320,6 +320,15 @@ def test_device_resident_chain(ek, orc, slab):
     th = ek.thermo.potential_temperature(dt, dp)
     assert_parity(ek.thermo.temperature_from_potential_temperature(th, dp).to_host(), t, "f32", "theta round trip",
                   rtol=1e-6)
+    # device-resident level vector and scalar operands are used in place (no host round trip)
+    pl = np.linspace(2e4, 1e5, t.shape[0]).astype(np.float32)
+    dpl = ek.to_device(pl[:, None])
+    got = ek.thermo.relative_humidity_from_specific_humidity(dt, dq, dpl)
+    assert isinstance(got, ek.DeviceArray)
+    assert_parity(got.to_host(), orc.relative_humidity_from_specific_humidity(t, q, pl[:, None]), "f32",
+                  "device-resident level vector")
+    got = ek.thermo.potential_temperature(dt, ek.to_device(np.float32(9e4)))
+    assert_parity(got.to_host(), orc.potential_temperature(t, np.float32(9e4)), "f32", "device-resident scalar")
 
 
 @pytest.mark.parametrize("tag,dt", [("f32", np.float32), ("f64", np.float64)])
