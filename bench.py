@@ -295,9 +295,9 @@ def main():
         def sync():
             _ffi.check(lib.ekm_sync(dev))
 
-        ev0, ev1 = C.c_void_p(), C.c_void_p()
-        _ffi.check(lib.ekm_event_create(dev, C.byref(ev0)))
-        _ffi.check(lib.ekm_event_create(dev, C.byref(ev1)))
+        evs = [C.c_void_p() for _ in range(args.steps + 1)]  # one event before each launch + one at the end
+        for e in evs:
+            _ffi.check(lib.ekm_event_create(dev, C.byref(e)))
 
     for _ in range(args.warmup):
         step()
@@ -305,12 +305,12 @@ def main():
     dist.barrier()
     sync()
     t0 = time.perf_counter()
-    if not args.dry_run:
-        _ffi.check(lib.ekm_event_record(dev, ev0, None))  # same (default) stream the kernels are launched on
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        if not args.dry_run:
+            _ffi.check(lib.ekm_event_record(dev, evs[k], None))  # same (default) stream the kernels are launched on
         step()
     if not args.dry_run:
-        _ffi.check(lib.ekm_event_record(dev, ev1, None))
+        _ffi.check(lib.ekm_event_record(dev, evs[-1], None))
     sync()
     dist.barrier()
     sync()
@@ -319,8 +319,12 @@ def main():
 
     if not args.dry_run:
         ms = C.c_float()
-        _ffi.check(lib.ekm_event_elapsed_ms(dev, ev0, ev1, C.byref(ms)))
+        _ffi.check(lib.ekm_event_elapsed_ms(dev, evs[0], evs[-1], C.byref(ms)))
         kernel_ms = dist.reduce(ms.value / args.steps, "max")  # average launch duration, slowest rank
+        per_launch = []
+        for k in range(args.steps):
+            _ffi.check(lib.ekm_event_elapsed_ms(dev, evs[k], evs[k + 1], C.byref(ms)))
+            per_launch.append(ms.value)
         if dist.rank == 0:
             parity = check_parity(args, t, q, p, plev, outs, n_local, first, nlev, np_dtype, hyb)
 
@@ -332,7 +336,9 @@ def main():
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles(args, n_local),
                     "kernel": entry, "bytes_per_point": bpp, "points_per_launch": n_local,
-                    "kernel_ms": round(kernel_ms, 4)}
+                    "kernel_ms": round(kernel_ms, 4),
+                    "kernel_ms_median": round(float(np.median(per_launch)), 4),
+                    "kernel_ms_min": round(float(np.min(per_launch)), 4)}
             if args.workload.startswith("wetbulb"):
                 # honest label: these kernels are limited by VALU issue (transcendentals at 1/4 rate), not by HBM
                 roof["limiter"] = "valu-issue (DESIGN.md section 4); frac is still quoted against the HBM roofline"
