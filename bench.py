@@ -62,12 +62,14 @@ def parse():
     ap.add_argument("--pmode", default="field", choices=["field", "level", "hybrid"],
                     help="pressure as a full field, as the 137-level vector staged in LDS, or formed in the kernel "
                          "from surface pressure and the IFS L137 A/B tables (hybrid model levels)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: one full global field per GPU; strong: one global field split across GPUs")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="strong: ONE global field split across the GPUs (BASELINE.json config 5; the default for "
+                         "N > 1); weak: one full global field per GPU (the only reading at N = 1, and its label there)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--levels", type=int, default=NLEV, help="levels per field (137 = the named config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="points per worker for the CPU baseline")
+    ap.add_argument("--cpu-slab-levels", type=int, default=8,
+                    help="levels (1800 x 3600 points each) of the slab the single-core CPU baseline runs on")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise rendezvous/sharding/reporting without touching a GPU (CI on CPU); value is null")
     ap.add_argument("--tiles", type=int, default=0)
@@ -99,41 +101,64 @@ def oracle_call(workload, t, q, p):
     raise KeyError(workload)
 
 
+CPU_BUDGET_S = 30.0  # the CPU baseline stops repeating once a leg has used this much time
+
+
+def _usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def _cpu_worker(job):
-    workload, npts, seed, dtype = job
+    workload, nlev, npts, seed, dtype, reps = job
     from oracle import synthetic
 
-    t, q, p, _ = synthetic.make_fields(8, npts // 8, dtype=np.dtype(dtype), seed=seed)
+    t, q, p, _ = synthetic.make_fields(nlev, npts, dtype=np.dtype(dtype), seed=seed)
     t, q, p = t.ravel(), q.ravel(), p.ravel()
-    best = float("inf")
-    for _ in range(2):
+    best, done, start = float("inf"), 0, time.perf_counter()
+    while done < reps and (done == 0 or time.perf_counter() - start < CPU_BUDGET_S):  # bounded: stop early on a slow host
         t0 = time.perf_counter()
         oracle_call(workload, t, q, p)
         best = min(best, time.perf_counter() - t0)
-    return t.size, best
+        done += 1
+    return t.size, best, done
 
 
-def cpu_baseline(workload, sample, dtype):
-    """The NumPy oracle (same operator sequence as the reference) on the host cores: one
-    process per core, each on its own slab of the benchmark distribution.  Must run before
-    this process initialises HIP (fork)."""
+def cpu_baseline(workload, slab_levels, dtype, reps=3):
+    """The NumPy oracle (same operator sequence as the reference; kind "port") on the host cores, on the
+    sample BASELINE.md section 3 names: an 8-level slab of the benchmark atmosphere (8 x 1800 x 3600 =
+    51.84 M points).  Two figures, best of `reps` each: one process on the whole slab ("NumPy, 1 core":
+    NumPy ufuncs are single-threaded) and one level (6.48 M points) per worker on every usable core at
+    once.  Must run before this process initialises HIP (fork)."""
     import multiprocessing as mp
 
-    cores = max(1, min(os.cpu_count() or 1, 16))
-    n1, t1 = _cpu_worker((workload, sample, 1, dtype))
-    jobs = [(workload, sample, 100 + i, dtype) for i in range(cores)]
+    cores = _usable_cores()
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(cores) as pool:
-        res = pool.map(_cpu_worker, jobs)
+        # the single-core run has the machine to itself first, then all workers run concurrently
+        n1, t1, reps1 = pool.apply(_cpu_worker, ((workload, slab_levels, INNER, 1, dtype, reps),))
+        res = pool.map(_cpu_worker, [(workload, 1, INNER, 100 + i, dtype, reps) for i in range(cores)], chunksize=1)
     wall = time.perf_counter() - t0
     pts = sum(r[0] for r in res)
     slowest = max(r[1] for r in res)
     return {
         "value": pts / slowest, "unit": "grid-points/s", "cores": cores, "kind": "port",
-        "value_1core": n1 / t1,
-        "sample": f"{cores} workers x {sample} points of the synthetic atmosphere (8 levels each), NumPy oracle "
-                  f"oracle/thermo_oracle.py ({workload}), best of 2 per worker, all workers concurrent; "
-                  f"pool wall {wall:.1f} s",
+        "value_1core": n1 / t1, "os_cpu_count": os.cpu_count(),
+        "repetitions": {"1core": reps1, "all_cores": min(r[2] for r in res)},
+        "sample": f"NumPy oracle oracle/thermo_oracle.py ({workload}) on the synthetic atmosphere: 1 core = one process "
+                  f"on a {slab_levels}-level slab ({n1} points); all cores = {cores} concurrent workers x one level "
+                  f"({INNER} points) each; best of up to {reps} (a leg stops repeating after {CPU_BUDGET_S:.0f} s); os.cpu_count() = {os.cpu_count()}, usable = {cores}; "
+                  f"wall {wall:.1f} s incl. input generation",
     }
 
 
@@ -171,9 +196,57 @@ class Dist:
         self.td.all_reduce(t, op=getattr(self.td.ReduceOp, op.upper()))
         return float(t[0])
 
+    def gather(self, values):
+        """Every rank's list of floats, as a list of lists (rank order)."""
+        if not self.td:
+            return [list(map(float, values))]
+        import torch
+
+        mine = torch.tensor(list(map(float, values)), dtype=torch.float64)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.td.all_gather(out, mine)
+        return [o.tolist() for o in out]
+
     def close(self):
         if self.td:
             self.td.destroy_process_group()
+
+
+COLUMN_WORKLOADS = ("hybrid_levels", "geopotential")
+
+
+def plan_shard(workload, pmode, scaling, rank, world, nlev=NLEV, inner=INNER):
+    """Which part of the global [nlev, inner] field rank `rank` of `world` owns.
+
+    weak:   every rank owns one whole field (n_total = world fields).
+    strong: ONE field, no halo, no exchange (BASELINE.json config 5):
+      * p a full field: the flat grid-point range cut by `shard_bounds` (64-B aligned starts);
+      * p a level vector / hybrid levels: cut on level boundaries (137 levels -> 18/17/17/... per GPU at 8),
+        so a shard's pressure operand is the contiguous sub-vector (sub-table) of its levels;
+      * the column workloads (hybrid_levels, geopotential: every column needs all its levels): cut along
+        the horizontal axis, each rank holding [nlev, its columns].
+    Returns first (flat index of the shard's first point in the global field; column shards: first column),
+    n_local, n_total, lev0/lev1 (level range), col0/col1 (column range)."""
+    from ekm_hip._engine import leading_axis_bounds
+    from ekm_hip.device import shard_bounds
+
+    n_field = nlev * inner
+    d = dict(lev0=0, lev1=nlev, col0=0, col1=inner, first=0, n_local=n_field, n_total=n_field * world, cut="none")
+    if scaling == "weak" or world == 1:
+        if scaling != "weak":
+            d["n_total"] = n_field
+        return d
+    d["n_total"] = n_field
+    if workload in COLUMN_WORKLOADS:
+        lo, hi = shard_bounds(inner, world)[rank]
+        d.update(col0=lo, col1=hi, first=lo, n_local=nlev * (hi - lo), cut="columns")
+    elif pmode in ("level", "hybrid"):
+        lo, hi = leading_axis_bounds(nlev, world)[rank]
+        d.update(lev0=lo, lev1=hi, first=lo * inner, n_local=(hi - lo) * inner, cut="levels")
+    else:
+        lo, hi = shard_bounds(n_field, world)[rank]
+        d.update(first=lo, n_local=hi - lo, lev0=lo // inner, lev1=-(-hi // inner), cut="grid points")
+    return d
 
 
 def main():
@@ -194,22 +267,17 @@ def main():
         bpp -= itemsize  # p is not read per point (hybrid: sp is 1/137 of a field and served from cache)
     nlev = args.levels
     n_field = nlev * INNER
-    if args.scaling == "weak":
-        first, n_local = 0, n_field          # every rank owns one whole global field
-        n_total = n_field * dist.world
-    else:
-        from ekm_hip.device import shard_bounds
-
-        if dist.world > 1 and (args.pmode != "field" or args.workload in ("hybrid_levels", "geopotential")):
-            sys.exit("--scaling strong cuts the flat grid-point range and needs --pmode field; the level / hybrid "
-                     "pressure modes and the column workloads run one whole field per GPU (--scaling weak)")
-        lo, hi = shard_bounds(n_field, dist.world)[dist.rank]
-        first, n_local = lo, hi - lo
-        n_total = n_field
+    if args.scaling == "auto":
+        args.scaling = "strong" if dist.world > 1 else "weak"
+    if args.workload == "geopotential":
+        args.pmode = "hybrid"
+    sh = plan_shard(args.workload, args.pmode, args.scaling, dist.rank, dist.world, nlev)
+    first, n_local, n_total = sh["first"], sh["n_local"], sh["n_total"]
 
     cpu = None
-    if dist.rank == 0 and dist.world == 1 and not args.no_cpu_baseline and not args.dry_run:
-        cpu = cpu_baseline(args.workload, args.cpu_sample, np_dtype)  # before HIP is initialised (fork)
+    if (dist.rank == 0 and dist.world == 1 and not args.no_cpu_baseline and not args.dry_run
+            and args.workload not in COLUMN_WORKLOADS):
+        cpu = cpu_baseline(args.workload, args.cpu_slab_levels, np_dtype)  # before HIP is initialised (fork)
 
     kernel_ms, parity = None, None
     if args.dry_run:
@@ -227,6 +295,8 @@ def main():
         if args.tiles or args.unroll:
             _ffi.check(lib.ekm_set_tuning(args.tiles, args.unroll))
         shape = (n_local,)
+        lev0, lev1, col0, col1 = sh["lev0"], sh["lev1"], sh["col0"], sh["col1"]
+        nlev_loc, ncol = lev1 - lev0, col1 - col0   # this shard's levels / columns
         t = DeviceArray.empty(shape, np_dtype, dev)
         q = DeviceArray.empty(shape, np_dtype, dev)
         p = DeviceArray.empty(shape, np_dtype, dev) if args.pmode == "field" else None
@@ -234,22 +304,23 @@ def main():
         plev = DeviceArray.empty((nlev,), np_dtype, dev)
         _ffi.check(getattr(lib, f"ekm_synth_levels_{args.dtype}")(dev, None, plev.ptr, nlev))
         hyb = None
-        if args.workload == "geopotential":
-            args.pmode = "hybrid"
         if args.pmode == "hybrid" or args.workload == "hybrid_levels":
-            # IFS L137 half-level tables (data recorded from the reference's conf/ifs_levels_conf.json)
-            assert first == 0 and nlev <= 137, "hybrid mode: whole fields only"
+            # IFS L137 half-level tables (data recorded from the reference's conf/ifs_levels_conf.json); a level
+            # shard takes the half levels lev0 .. lev1 of the table, a column shard its columns of sp
+            assert nlev <= 137, "hybrid mode: at most the 137 IFS levels"
             g = np.load(os.path.join(ROOT, "tests", "golden", "vertical_golden.npz"))
-            A, B = g["coef.137.A"][137 - nlev:], g["coef.137.B"][137 - nlev:]
-            rng = np.random.default_rng(seed)
+            A = g["coef.137.A"][137 - nlev:][lev0:lev1 + 1]
+            B = g["coef.137.B"][137 - nlev:][lev0:lev1 + 1]
+            rng = np.random.default_rng(20260313 if args.scaling == "strong" else seed)
             sp_host = (101325.0 * (1.0 - 0.35 * rng.random(INNER) ** 3)).astype(np_dtype)  # mostly near sea level, some orography
+            sp_host = np.ascontiguousarray(sp_host[col0:col1])
             hyb = dict(A=DeviceArray.from_host(A.astype(np_dtype), dev), B=DeviceArray.from_host(B.astype(np_dtype), dev),
                        sp=DeviceArray.from_host(sp_host, dev), Ah=A, Bh=B, sph=sp_host)
         if args.pmode == "hybrid":
             # t, q drawn around the hybrid-level pressure (materialised once, then dropped)
             ptmp = DeviceArray.empty(shape, np_dtype, dev)
             _ffi.check(getattr(lib, f"ekm_pressure_on_hybrid_levels_{args.dtype}")(
-                dev, None, hyb["A"].ptr, hyb["B"].ptr, hyb["sp"].ptr, INNER, nlev, None, None, 1,
+                dev, None, hyb["A"].ptr, hyb["B"].ptr, hyb["sp"].ptr, ncol, nlev_loc, None, None, 1,
                 float(np.log(2)), ptmp.ptr, None, None, None))
             _ffi.check(getattr(lib, f"ekm_synth_fill_given_p_{args.dtype}")(dev, None, t.ptr, q.ptr, ptmp.ptr, first,
                                                                              n_local, seed))
@@ -266,12 +337,10 @@ def main():
         if p is not None:
             op_p = F(p.ptr, _ffi.FIELD, 0, 0, 0)
         elif args.pmode == "hybrid":
-            op_p = F(hyb["sp"].ptr, _ffi.HYBRID_FULL, 0, nlev, INNER, hyb["A"].ptr, hyb["B"].ptr)
-        else:  # level vector: index = (first + i) // INNER; shards start on a level boundary only at rank 0,
-            # so a shard passes the sub-vector starting at its first level and an offset-free inner
-            assert first % INNER == 0 or args.scaling == "weak", "level mode needs level-aligned shards"
-            lev0 = first // INNER
-            op_p = F(plev.ptr + lev0 * itemsize, _ffi.LEVEL_MAJOR, 0, nlev - lev0, INNER)
+            op_p = F(hyb["sp"].ptr, _ffi.HYBRID_FULL, 0, nlev_loc, ncol, hyb["A"].ptr, hyb["B"].ptr)
+        else:  # level vector: a shard starts on a level boundary (plan_shard) and passes the sub-vector of its levels
+            assert first % INNER == 0, "level mode needs level-aligned shards"
+            op_p = F(plev.ptr + lev0 * itemsize, _ffi.LEVEL_MAJOR, 0, nlev_loc, INNER)
         operands = {"pipeline_full": (op_t, op_q, op_p), "pipeline_svp_td_rh": (op_t, op_q, op_p),
                     "wet_bulb_temperature_from_specific_humidity": (op_t, op_q, op_p),
                     "relative_humidity_from_specific_humidity": (op_t, op_q, op_p),
@@ -283,10 +352,10 @@ def main():
         if args.workload == "geopotential":
             zs_host = np.maximum(0.0, (101325.0 - hyb["sph"].astype(np.float64)) / 1.2).astype(np_dtype)  # g*z ~ dp / rho
             hyb["zs"], hyb["zsh"] = DeviceArray.from_host(zs_host, dev), zs_host
-            cargs = [dev, None, hyb["A"].ptr, hyb["B"].ptr, hyb["sp"].ptr, hyb["zs"].ptr, t.ptr, q.ptr, INNER, nlev, 1,
+            cargs = [dev, None, hyb["A"].ptr, hyb["B"].ptr, hyb["sp"].ptr, hyb["zs"].ptr, t.ptr, q.ptr, ncol, nlev, 1,
                      float(np.log(2)), 1, outs[0].ptr]
         if args.workload == "hybrid_levels":
-            cargs = [dev, None, hyb["A"].ptr, hyb["B"].ptr, hyb["sp"].ptr, INNER, nlev, None, None, 1,
+            cargs = [dev, None, hyb["A"].ptr, hyb["B"].ptr, hyb["sp"].ptr, ncol, nlev, None, None, 1,
                      float(np.log(2)), outs[0].ptr, None, None, None]
 
         def step():
@@ -317,16 +386,23 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = dist.reduce(elapsed, "max")
 
+    ndev_seen, dev_used, my_ms = -1, -1, float("nan")
     if not args.dry_run:
         ms = C.c_float()
         _ffi.check(lib.ekm_event_elapsed_ms(dev, evs[0], evs[-1], C.byref(ms)))
-        kernel_ms = dist.reduce(ms.value / args.steps, "max")  # average launch duration, slowest rank
+        my_ms = ms.value / args.steps
+        kernel_ms = dist.reduce(my_ms, "max")  # average launch duration, slowest rank
         per_launch = []
         for k in range(args.steps):
             _ffi.check(lib.ekm_event_elapsed_ms(dev, evs[k], evs[k + 1], C.byref(ms)))
             per_launch.append(ms.value)
+        ndev_seen, dev_used = ndev, dev
         if dist.rank == 0:
-            parity = check_parity(args, t, q, p, plev, outs, n_local, first, nlev, np_dtype, hyb)
+            parity = check_parity(args, t, q, p, plev, outs, sh, nlev, np_dtype, hyb)
+    # what every rank did: [kernel ms per launch, points it owns, hipGetDeviceCount() it saw, device it used]
+    per_rank = [dict(rank=r, kernel_ms=None if v[0] != v[0] else round(v[0], 4), points=int(v[1]),
+                     hip_device_count=int(v[2]), device=int(v[3]))
+                for r, v in enumerate(dist.gather([my_ms, n_local, ndev_seen, dev_used]))]
 
     if dist.rank == 0:
         value = None if args.dry_run else n_total * args.steps / elapsed
@@ -335,6 +411,9 @@ def main():
             achieved = bpp * n_local / (kernel_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles(args, n_local),
+                    "traffic_source": "profiles/traffic_latest.json: FETCH_SIZE x 2 (gfx950) + WRITE_SIZE from separate "
+                                      "rocprofv3 --pmc passes of this command (tools/profile_gpu.sh), committed; "
+                                      "not re-measured in this run",
                     "kernel": entry, "bytes_per_point": bpp, "points_per_launch": n_local,
                     "kernel_ms": round(kernel_ms, 4),
                     "kernel_ms_median": round(float(np.median(per_launch)), 4),
@@ -349,9 +428,10 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"{desc} on {nlev}x{NLAT}x{NLON} {args.dtype} "
-                                   f"({'one field per GPU' if args.scaling == 'weak' else 'one field split by grid point'}),"
+                                   f"({'one field per GPU' if args.scaling == 'weak' else f'ONE field split across {dist.world} GPUs by ' + sh['cut']}),"
                                    f" p as {dict(field='full field', level='137-level vector in LDS', hybrid='hybrid levels formed in-kernel from sp + A/B tables')[args.pmode]}",
-                       "entry_point": f"ekm_{entry}_{args.dtype}", "points_per_gpu": n_local, "p_mode": args.pmode},
+                       "entry_point": f"ekm_{entry}_{args.dtype}", "points_per_gpu": n_total // dist.world, "p_mode": args.pmode,
+                       "points_total": n_total, "shard_cut": sh["cut"], "per_rank": per_rank},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
         if args.dry_run:
@@ -360,14 +440,17 @@ def main():
     dist.close()
 
 
-def check_parity(args, t, q, p, plev, outs, n_local, first, nlev, np_dtype, hyb=None):
-    """GPU outputs of the timed arrays vs the oracle on 256-point windows of 32 levels."""
+def check_parity(args, t, q, p, plev, outs, sh, nlev, np_dtype, hyb=None):
+    """GPU outputs of the timed arrays (this rank's shard) vs the oracle on 256-point windows of 32 levels."""
     tol = 1e-4 if args.dtype == "f32" else 1e-6
+    first, n_local, lev0 = sh["first"], sh["n_local"], sh["lev0"]
+    by_columns = sh["cut"] == "columns"
+    ncol = sh["col1"] - sh["col0"]  # row length of this shard's [level, column] layout
     if args.workload == "geopotential":  # whole columns: 64 columns x all levels
         from oracle import vertical_oracle as vo
 
         c0, nc = 4321, 64
-        col = lambda a: np.stack([a.flat_slice(k * INNER + c0, k * INNER + c0 + nc).to_host() for k in range(nlev)])  # noqa: E731
+        col = lambda a: np.stack([a.flat_slice(k * ncol + c0, k * ncol + c0 + nc).to_host() for k in range(nlev)])  # noqa: E731
         want = vo.geopotential_on_hybrid_levels(col(t), col(q), hyb["zsh"][c0:c0 + nc], hyb["Ah"].astype(np_dtype),
                                                 hyb["Bh"].astype(np_dtype), hyb["sph"][c0:c0 + nc])
         got = col(outs[0]).astype(np.float64)
@@ -389,7 +472,7 @@ def check_parity(args, t, q, p, plev, outs, n_local, first, nlev, np_dtype, hyb=
     if args.pmode == "hybrid" and args.workload != "hybrid_levels":
         lo_lev = min(36, nlev - 1)  # above ~25 hPa the synthetic humidity is unphysical
     for lev in np.linspace(lo_lev, nlev - 1, 32).round().astype(int):
-        lo = int(lev) * INNER - first + 4321
+        lo = int(lev) * ncol + 4321 if by_columns else int(lev) * INNER - first + 4321
         if 0 <= lo and lo + 256 <= n_local:
             wins.append((int(lev), lo))
     if not wins:
@@ -400,7 +483,7 @@ def check_parity(args, t, q, p, plev, outs, n_local, first, nlev, np_dtype, hyb=
         from oracle import vertical_oracle as vo
 
         pf = vo.pressure_on_hybrid_levels(hyb["Ah"].astype(np_dtype), hyb["Bh"].astype(np_dtype), hyb["sph"][4321:4321 + 256])
-        hp = np.concatenate([pf[lev] for lev, _ in wins]).astype(np_dtype)
+        hp = np.concatenate([pf[lev - lev0] for lev, _ in wins]).astype(np_dtype)
     elif p is not None:
         hp = np.concatenate([p.flat_slice(lo, lo + 256).to_host() for _, lo in wins])
     else:
@@ -415,21 +498,39 @@ def check_parity(args, t, q, p, plev, outs, n_local, first, nlev, np_dtype, hyb=
 
         edge = conditioning.newton_regime_boundary("pipeline_full", [ht, hq, hp], {},
                                                    1e-5 if args.dtype == "f32" else 1e-13)
-    worst, nan_mismatch = 0.0, 0
+    bis = args.workload == "wetbulb_bisect"
+    noisy = None
+    if bis:  # points where sign() of the reference's own residual is rounding noise are excluded and counted
+        from oracle import conditioning
+
+        noisy = conditioning.bisect_sign_noise("wet_bulb_temperature_from_specific_humidity", [ht, hq, hp], {},
+                                               2e-6 if args.dtype == "f32" else 1e-13)
+    worst, nan_mismatch, worst_abs = 0.0, 0, 0.0
     for k, (o, w) in enumerate(zip(outs, want)):
         g = np.concatenate([o.flat_slice(lo, lo + 256).to_host() for _, lo in wins]).astype(np.float64)
         w = np.asarray(w, dtype=np.float64)
         if edge is not None and k == len(want) - 1:
             g, w = g[~edge], w[~edge]
+        if noisy is not None:
+            g, w = g[~noisy], w[~noisy]
         nan_mismatch += int((np.isnan(g) != np.isnan(w)).sum())
         with np.errstate(all="ignore"):
-            r = np.abs(g - w) / np.abs(w)
-        r = r[np.isfinite(r)]
+            a = np.abs(g - w)
+            r = a / np.abs(w)
+        a, r = a[np.isfinite(a)], r[np.isfinite(r)]
         worst = max(worst, float(r.max()) if r.size else 0.0)
-    bis = args.workload == "wetbulb_bisect"
-    return {"points": int(ht.size), "max_rel_err": worst, "nan_mismatch": nan_mismatch, "tolerance": tol,
-            "excluded_regime_boundary_points": int(edge.sum()) if edge is not None else 0,
-            "ok": bool(nan_mismatch == 0 and (worst <= tol or bis))}
+        worst_abs = max(worst_abs, float(a.max()) if a.size else 0.0)
+    res = {"points": int(ht.size), "max_rel_err": worst, "nan_mismatch": nan_mismatch, "tolerance": tol,
+           "excluded_regime_boundary_points": int(edge.sum()) if edge is not None else 0,
+           "ok": bool(nan_mismatch == 0 and worst <= tol)}
+    if bis:
+        # the 12-step sign search is quantised to 120/4096 K: a rounding-level change of one residual moves
+        # the answer by at most two quanta (the reference's own tests allow rtol 1e-3 here)
+        quantum = 120.0 / 4096.0
+        res.update(tolerance="2 quanta of the 12-step search = 0.0586 K absolute", max_abs_err=worst_abs,
+                   excluded_sign_noise_points=int(noisy.sum()),
+                   ok=bool(nan_mismatch == 0 and worst_abs <= 2 * quantum * (1 + 1e-6)))
+    return res
 
 
 def traffic_from_profiles(args, n_local):
