@@ -16,11 +16,14 @@ from .device import (  # noqa: F401
     device_count,
     device_info,
     empty_cache,
+    memory_stats,
+    order_streams,
     multi_gpu,
     set_device,
     set_stream,
     shard_bounds,
     stream_create,
+    stream_destroy,
     synchronize,
     to_device,
 )
@@ -28,3 +31,4 @@ from .device import (  # noqa: F401
 __version__ = "0.1.0"
 from .vertical import HybridPressure  # noqa: F401,E402
 from .dlpack import from_dlpack  # noqa: F401,E402
+from ._engine import release_streams  # noqa: F401,E402

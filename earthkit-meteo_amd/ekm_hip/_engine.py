@@ -12,6 +12,8 @@ DeviceArrays; broadcast operands (a scalar, a level vector along the leading or
 trailing axes) are passed to the kernels as such instead of being materialised.
 """
 import ctypes as C
+import os
+import threading
 
 import numpy as np
 
@@ -30,8 +32,6 @@ _STREAM_BYTES = 256 << 20  # total input bytes from which a single-GPU NumPy cal
 def _pretouch(arrays):
     """Fault in the pages of fresh result arrays from a helper thread while the inputs upload
     (ekm_host_prefault runs outside the GIL, on a few threads of its own)."""
-    import threading
-
     lib = _ffi.lib()
 
     def work():
@@ -134,23 +134,19 @@ class _Plan:
 
 
 def run(name, args, ints=(), eps=None, dtype=None):
-    """Launch entry point `name` on `args`; returns a tuple of outputs.  Inside `ekm_hip.multi_gpu()`
-    NumPy inputs are split along their leading axis across the selected GPUs (one host thread each)."""
+    """Launch entry point `name` on `args`; returns a tuple of outputs.  NumPy inputs that are large
+    (>= 256 MB), or any NumPy inputs inside `ekm_hip.multi_gpu()`, are streamed through the GPU(s) in
+    slices of their leading axis with a bounded device working set (`_run_streamed`)."""
     from .device import current_devices
 
     devs = current_devices()
     numpy_only = not any(isinstance(a, (DeviceArray, HybridPressure)) for a in args)
-    if numpy_only and not (devs and len(devs) > 1):
-        # one GPU, large host arrays: eight slices on eight streams, so that the upload of one slice
-        # overlaps the download of another (PCIe is full duplex: 19 ms instead of 23 ms for 3 x 207 MB
-        # in, 3 x 207 MB out)
-        nbytes = sum(np.asarray(a).nbytes for a in args if np.ndim(a) > 0)
-        if nbytes >= _STREAM_BYTES:
-            devs = [current_device()] * 8
-    if devs and len(devs) > 1 and numpy_only:
-        sharded = _run_sharded(name, args, ints, eps, devs)
-        if sharded is not None:
-            return sharded
+    if numpy_only:
+        multi = bool(devs) and len(devs) > 1
+        if multi or sum(np.asarray(a).nbytes for a in args if np.ndim(a) > 0) >= _STREAM_BYTES:
+            streamed = _run_streamed(name, args, ints, eps, dtype, devs if multi else [current_device()])
+            if streamed is not None:
+                return streamed
     return _run_single(name, args, ints, eps, dtype)
 
 
@@ -166,24 +162,83 @@ def leading_axis_bounds(n0, nshards):
 
 
 _streams = {}
+_streams_lock = threading.Lock()
+_MAX_LANES = 8            # slices in flight per GPU when memory allows (upload of one overlaps download of another)
+_MIN_SLICE_BYTES = 16 << 20  # do not cut finer than this: small copies waste PCIe bandwidth
 
 
-def _shard_stream(dev, key):
-    """One long-lived stream per (device, shard slot)."""
+def _lane_stream(dev, slot):
+    """One long-lived stream per (device, lane slot 0.._MAX_LANES-1); `release_streams()` destroys them."""
     from .device import stream_create
 
-    k = (dev, key)
-    if k not in _streams:
-        _streams[k] = stream_create(dev)
-    return _streams[k]
+    with _streams_lock:
+        k = (dev, slot)
+        if k not in _streams:
+            _streams[k] = stream_create(dev)
+        return _streams[k]
 
 
-def _run_sharded(name, args, ints, eps, devs):
-    """Grid points are independent: cut the broadcast result along its leading axis into one contiguous
-    block per GPU (for [level, lat, lon] fields: ~17 whole levels each on 8 GPUs), give every operand that
-    spans that axis the matching slice and every other operand (scalars, trailing-axis vectors) whole,
-    and run the blocks concurrently, one host thread per device, straight into slices of the result."""
-    import threading
+def release_streams():
+    """Destroy the lane streams of the streamed NumPy path (and return their cached blocks to HIP)."""
+    from .device import stream_destroy
+
+    with _streams_lock:
+        items = list(_streams.items())
+        _streams.clear()
+    for (dev, _slot), st in items:
+        stream_destroy(st, dev)
+
+
+def stream_budget_bytes(dev):
+    """Device bytes the streamed path may hold in flight on `dev`: 80 % of what is free now plus what our own
+    block cache holds, capped by EKM_STREAM_BUDGET_BYTES when set."""
+    from .device import _cache
+
+    free, total = C.c_size_t(), C.c_size_t()
+    _ffi.check(_ffi.lib().ekm_mem_info(dev, C.byref(free), C.byref(total)))
+    budget = int(0.8 * (free.value + _cache.cached_bytes(dev)))
+    cap = os.environ.get("EKM_STREAM_BUDGET_BYTES")
+    return min(budget, int(cap)) if cap else budget
+
+
+def plan_slices(rows, row_bytes, budget, max_lanes=_MAX_LANES, min_slice=_MIN_SLICE_BYTES):
+    """How to stream `rows` leading-axis rows of `row_bytes` device bytes each (inputs + outputs) through a
+    device working set of at most `budget` bytes: returns (lanes, nslices) -- `lanes` slices are in flight at
+    a time, each lane recycling its device blocks from slice to slice, and
+    lanes * ceil(rows / nslices) * row_bytes <= budget.
+      * everything fits: one slice per lane, up to `max_lanes` lanes, slices of at least `min_slice` bytes
+        (small copies waste PCIe bandwidth; a small call is one slice);
+      * it does not fit: as many lanes as the budget allows with slices of at least `min_slice` (8, 4), at
+        least two (double buffering) whatever the slice size; None if two single-row slices do not fit."""
+    total = rows * row_bytes
+    if total == 0:
+        return 1, 1
+    if total <= budget:
+        lanes = int(max(1, min(max_lanes, rows, total // min_slice)))
+        return lanes, lanes
+    for lanes in (8, 4, 2):
+        if lanes > max(max_lanes, 2) or lanes > rows:
+            continue
+        rows_per = (budget // lanes) // row_bytes
+        if rows_per < 1 or (lanes > 2 and rows_per * row_bytes < min_slice):
+            continue
+        return lanes, -(-rows // rows_per)
+    return None
+
+
+def _run_streamed(name, args, ints, eps, dtype, devs):
+    """Grid points are independent: cut the broadcast result along its leading axis, give every operand that
+    spans that axis the matching slice and every other operand (scalars, trailing-axis vectors) whole, and
+    stream the slices through the GPU(s) straight into slices of the result arrays.
+
+    * several GPUs (`multi_gpu()`): one contiguous block of rows per GPU (~17 whole levels each for
+      [137, lat, lon] fields on 8 GPUs), no exchange of any kind;
+    * per GPU: `lanes` host threads, each with its own stream, take slices from a queue -- the upload of one
+      slice overlaps the kernel and the download of others (PCIe is full duplex); the device blocks of a
+      finished slice go back to the block cache of that lane's stream and are reused by its next slice, so the
+      device working set is lanes x slice, chosen to fit `stream_budget_bytes` (fields larger than HBM stream
+      through; with a tight budget this degrades to two slices in flight, i.e. double buffering)."""
+    import queue
 
     from .device import set_device, set_stream
 
@@ -191,37 +246,62 @@ def _run_sharded(name, args, ints, eps, devs):
     shape = tuple(np.broadcast_shapes(*[h.shape for h in host]))
     if len(shape) == 0 or shape[0] < len(devs):
         return None
-    out_dtype, _ = _result_dtype(args)
+    out_dtype, cdtype = _result_dtype(args)
+    if dtype is not None:
+        out_dtype = cdtype = np.dtype(dtype)
     nout = len(OPS[name][1])
+    spans = [h.ndim == len(shape) and h.shape[0] == shape[0] for h in host]
+    row_pts = int(np.prod(shape[1:], dtype=np.int64))
+    # device bytes per leading-axis row: sliced inputs (a broadcast row still costs its own size) + outputs
+    row_bytes = (sum(int(np.prod(h.shape[1:], dtype=np.int64)) for h, sp in zip(host, spans) if sp) + nout * row_pts) * cdtype.itemsize
+    blocks = [b for b in leading_axis_bounds(shape[0], len(devs)) if b[1] > b[0]]
+    plans = []
+    for dev, (lo, hi) in zip(devs, blocks):
+        pl = plan_slices(hi - lo, max(row_bytes, 1), stream_budget_bytes(dev))
+        if pl is None:
+            raise _ffi.EkmError(f"{name}: one leading-axis row needs {row_bytes} B on the device, two do not fit the "
+                                f"streaming budget of {stream_budget_bytes(dev)} B on device {dev}")
+        plans.append(pl)
     outs = [np.empty(shape, out_dtype) for _ in range(nout)]
-    toucher = _pretouch(outs) if outs[0].nbytes >= _PRETOUCH_BYTES else None
-    bounds = [b for b in leading_axis_bounds(shape[0], len(devs)) if b[1] > b[0]]
     errors = []
 
-    def work(dev, lo, hi):
+    def lane(dev, slot, todo):
         try:
             set_device(dev)
-            set_stream(_shard_stream(dev, lo))  # own stream: shards on one GPU overlap upload / kernel / download
-            # operands that span the leading axis get the matching slice; everything else is passed as
-            # the caller gave it (a Python scalar must stay a weak scalar for the dtype promotion)
-            part = [h[lo:hi] if (h.ndim == len(shape) and h.shape[0] == shape[0]) else a for h, a in zip(host, args)]
-            _run_single(name, part, ints, eps, None, host_out=[o[lo:hi] for o in outs])
+            set_stream(_lane_stream(dev, slot))
+            while not errors:
+                try:
+                    lo, hi = todo.get_nowait()
+                except queue.Empty:
+                    return
+                # operands that span the leading axis get the matching slice; everything else is passed as
+                # the caller gave it (a Python scalar must stay a weak scalar for the dtype promotion)
+                part = [h[lo:hi] if sp else a for h, a, sp in zip(host, args, spans)]
+                dest = [o[lo:hi] for o in outs]
+                _run_single(name, part, ints, eps, dtype, host_out=dest,
+                            toucher=_pretouch(dest) if dest[0].nbytes >= _PRETOUCH_BYTES else None)
         except BaseException as exc:  # surfaced in the calling thread
             errors.append(exc)
 
-    threads = [threading.Thread(target=work, args=(d, lo, hi)) for d, (lo, hi) in zip(devs, bounds)]
+    threads = []
+    for dev, (lo, hi), (lanes, nslices) in zip(devs, blocks, plans):
+        todo = queue.Queue()
+        for a, b in leading_axis_bounds(hi - lo, nslices):
+            if b > a:
+                todo.put((lo + a, lo + b))
+        threads += [threading.Thread(target=lane, args=(dev, slot, todo)) for slot in range(lanes)]
     for th in threads:
         th.start()
     for th in threads:
         th.join()
-    if toucher is not None:
-        toucher.join()
     if errors:
         raise errors[0]
     return tuple(outs)
 
 
-def _run_single(name, args, ints=(), eps=None, dtype=None, host_out=None):
+def _run_single(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=None):
+    """One launch.  `host_out` (caller-owned NumPy destinations, e.g. slices of a result array) receives the
+    outputs directly; `toucher` is a thread prefaulting them, joined before anything is downloaded."""
     ins, outs, int_names, has_eps = OPS[name]
     assert len(args) == len(ins) and len(ints) == len(int_names)
     plan = _Plan(args, dtype)
@@ -233,17 +313,20 @@ def _run_single(name, args, ints=(), eps=None, dtype=None, host_out=None):
     temps = []  # device buffers owned by this call
     operands = []
     lds_bytes = 0
-    toucher = None
+    internal_out = False  # host_out allocated here (compute dtype) rather than supplied by the caller
     if not plan.on_device and host_out is None and plan.n * plan.dtype.itemsize >= _PRETOUCH_BYTES:
         # Large NumPy result: the pages of a fresh array fault on first touch, which slows the download
-        # from 56 to ~24 GB/s.  Fault them in from a helper thread while the inputs are uploading.
+        # from 56 to ~24 GB/s.  Fault them in from a helper thread while the inputs are uploading
+        # (ekm_host_prefault never changes the contents, and it is joined before the download anyway).
         host_out = [np.empty(plan.shape, plan.dtype) for _ in outs]
         toucher = _pretouch(host_out)
+        internal_out = True
     for k, a in enumerate(plan.host):
         if plan.hybrid and k == len(plan.host) - 1:
             hp = plan.hybrid[0]
             sp = a if isinstance(a, DeviceArray) and a.dtype == plan.dtype else DeviceArray.from_host(
                 np.ascontiguousarray(np.asarray(a), dtype=plan.dtype), device=dev)
+            sp.on(stream)
             tabs = [DeviceArray.from_host(x.astype(plan.dtype), device=dev) for x in (hp.A, hp.B)]
             temps.extend(tabs + ([sp] if sp is not a else []))
             inner = max(1, sp.size)
@@ -266,7 +349,8 @@ def _run_single(name, args, ints=(), eps=None, dtype=None, host_out=None):
                 cls = (_ffi.FIELD, 0, 0)
             darr = DeviceArray.from_host(np.ascontiguousarray(h, dtype=plan.dtype), device=dev)
             temps.append(darr)
-        operands.append(_ffi.Operand(darr.ptr, cls[0], 0, cls[1], cls[2]))
+        # .on(stream): an input last used on another stream makes this stream wait for that work (device-side)
+        operands.append(_ffi.Operand(darr.on(stream), cls[0], 0, cls[1], cls[2]))
 
     results = [DeviceArray.empty(plan.shape, plan.dtype, dev) for _ in outs]
     cargs = [dev, stream] + [C.byref(o) for o in operands] + [int(v) for v in ints]
@@ -293,7 +377,7 @@ def _run_single(name, args, ints=(), eps=None, dtype=None, host_out=None):
                 host_out[k][...] = h
                 h = host_out[k]
         r.free()
-        if plan.out_dtype != plan.dtype and host_out is None:
+        if plan.out_dtype != plan.dtype and (host_out is None or internal_out):
             h = h.astype(plan.out_dtype)
         host.append(h[()] if plan.all_scalar else h)
     for t in temps:

@@ -61,6 +61,7 @@ def _signatures():
         "ekm_stream_create": ([i, pvp], i), "ekm_stream_destroy": ([i, vp], i), "ekm_stream_sync": ([i, vp], i),
         "ekm_event_create": ([i, pvp], i), "ekm_event_destroy": ([i, vp], i),
         "ekm_event_record": ([i, vp, vp], i), "ekm_event_sync": ([i, vp], i),
+        "ekm_stream_wait_event": ([i, vp, vp], i),
         "ekm_event_elapsed_ms": ([i, vp, vp, C.POINTER(C.c_float)], i),
         "ekm_set_tuning": ([i, i], i), "ekm_get_tuning": ([C.POINTER(i), C.POINTER(i)], i),
         "ekm_synth_fill_f32": ([i, vp, vp, vp, vp, u64, sz, u64, u32, u64], i),

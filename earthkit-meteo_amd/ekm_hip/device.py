@@ -96,6 +96,31 @@ def stream_create(dev=None):
     return out.value
 
 
+def stream_destroy(stream, dev=None):
+    """Destroy a stream made by `stream_create` (cached blocks last used on it are returned to HIP first)."""
+    dev = current_device() if dev is None else dev
+    lib = _ffi.lib()
+    _ffi.check(lib.ekm_stream_sync(dev, stream))
+    _cache.drain(device=dev, stream=stream)
+    _ffi.check(lib.ekm_stream_destroy(dev, stream))
+
+
+def order_streams(dev, first, then):
+    """Make work submitted to stream `then` from now on wait for everything submitted to stream `first` so
+    far (an event on the device; the host does not wait).  Streams from `stream_create` are non-blocking:
+    nothing orders them against each other or against the default stream unless this is called."""
+    if first == then:
+        return
+    lib = _ffi.lib()
+    ev = C.c_void_p()
+    _ffi.check(lib.ekm_event_create(dev, C.byref(ev)))
+    try:
+        _ffi.check(lib.ekm_event_record(dev, ev, first))
+        _ffi.check(lib.ekm_stream_wait_event(dev, then, ev))
+    finally:
+        _ffi.check(lib.ekm_event_destroy(dev, ev))  # released by HIP once the event has completed
+
+
 def synchronize(dev=None):
     _ffi.check(_ffi.lib().ekm_sync(current_device() if dev is None else dev))
 
@@ -106,8 +131,9 @@ class _BlockCache:
     hipMalloc / hipFree cost 50-500 us each and hipFree synchronises the device; a thermo call on
     NumPy input needs one block per operand and per output, so small and medium calls are dominated
     by them.  Freed blocks are kept (up to `limit` bytes per device) and handed out again for
-    requests of the same bucket.  Blocks are reused only on the stream they were last used on, so
-    stream order alone makes reuse safe.
+    requests of the same bucket.  A block is filed under the stream it was LAST USED on (every launch and
+    copy records it, `_Allocation.touch`, and orders itself after the previous stream's work when the
+    stream changes), and handed out again only for that stream: stream order alone makes reuse safe.
     """
 
     def __init__(self):
@@ -115,6 +141,15 @@ class _BlockCache:
         self.bytes = {}     # device -> cached bytes
         self.limit = int(os.environ.get("EKM_CACHE_BYTES", str(16 << 30)))
         self.lock = threading.Lock()
+        self.live = {}      # device -> bytes of blocks currently handed out to arrays
+        self.peak = {}      # device -> high-water mark of `live` since the last reset
+
+    def note(self, device, delta):
+        with self.lock:
+            v = self.live.get(device, 0) + delta
+            self.live[device] = v
+            if v > self.peak.get(device, 0):
+                self.peak[device] = v
 
     @staticmethod
     def bucket(nbytes):
@@ -140,12 +175,20 @@ class _BlockCache:
             self.bytes[device] = self.bytes.get(device, 0) + bucket
             return True
 
-    def drain(self):
+    def drain(self, device=None, stream=Ellipsis):
+        """Return cached blocks to HIP: all of them, or those of one device / one (device, stream)."""
         with self.lock:
-            items, self.free, self.bytes = self.free, {}, {}
-        for (device, _stream, _bucket), ptrs in items.items():
+            keys = [k for k in self.free if (device is None or k[0] == device) and (stream is Ellipsis or k[1] == stream)]
+            items = {k: self.free.pop(k) for k in keys}
+            for (dev, _s, bucket), ptrs in items.items():
+                self.bytes[dev] = self.bytes.get(dev, 0) - bucket * len(ptrs)
+        for (dev, _stream, _bucket), ptrs in items.items():
             for ptr in ptrs:
-                _ffi.check(_ffi.lib().ekm_free(device, ptr))
+                _ffi.check(_ffi.lib().ekm_free(dev, ptr))
+
+    def cached_bytes(self, device):
+        with self.lock:
+            return self.bytes.get(device, 0)
 
 
 _cache = _BlockCache()
@@ -156,14 +199,35 @@ def empty_cache():
     _cache.drain()
 
 
-class _Allocation:
-    """Owns one device block; returned to the block cache when the last view goes away."""
+def memory_stats(dev=None, reset_peak=False):
+    """Bytes of device blocks held by live arrays now / at most since the last reset, and bytes parked in the
+    block cache, for one GPU (what `torch.cuda.memory_stats` is to torch)."""
+    dev = current_device() if dev is None else dev
+    with _cache.lock:
+        out = {"live_bytes": _cache.live.get(dev, 0), "peak_live_bytes": _cache.peak.get(dev, 0),
+               "cached_bytes": _cache.bytes.get(dev, 0)}
+        if reset_peak:
+            _cache.peak[dev] = _cache.live.get(dev, 0)
+    return out
 
-    __slots__ = ("ptr", "nbytes", "device", "stream", "bucket", "__weakref__")
+
+class _Allocation:
+    """Owns one device block; returned to the block cache when the last view goes away.
+
+    `stream` is the stream the block was last used on.  `touch(stream)` is called for every launch / copy
+    that reads or writes the block: when the stream changes, the new stream is first ordered after the
+    work already submitted on the old one (`order_streams`), so (a) an array produced on one stream and
+    consumed on another is read only after it has been written, and (b) when the block is freed, all work
+    on it is ordered before the tail of `stream`, the list it is cached under.
+    """
+
+    __slots__ = ("ptr", "nbytes", "device", "stream", "bucket", "exported", "_lock", "__weakref__")
 
     def __init__(self, nbytes, device):
         self.device, self.nbytes, self.stream = device, nbytes, current_stream()
         self.bucket = _BlockCache.bucket(nbytes)
+        self.exported = False  # handed to a DLPack consumer, whose streams are unknown here
+        self._lock = threading.Lock()
         ptr = _cache.take(device, self.stream, self.bucket)
         if ptr is None:
             out = C.c_void_p()
@@ -173,11 +237,21 @@ class _Allocation:
                 _ffi.check(_ffi.lib().ekm_malloc(device, self.bucket, C.byref(out)))
             ptr = out.value
         self.ptr = ptr
+        _cache.note(device, self.bucket)
+
+    def touch(self, stream):
+        with self._lock:
+            if stream != self.stream:
+                order_streams(self.device, self.stream, stream)
+                self.stream = stream
 
     def free(self):
         if self.ptr:
             ptr, self.ptr = self.ptr, None
-            if not _cache.give(self.device, self.stream, self.bucket, ptr):
+            _cache.note(self.device, -self.bucket)
+            # a block a DLPack consumer has used goes back to HIP (hipFree waits for the device): the
+            # consumer's streams are not known here, so stream-ordered reuse cannot be guaranteed
+            if self.exported or not _cache.give(self.device, self.stream, self.bucket, ptr):
                 _ffi.check(_ffi.lib().ekm_free(self.device, ptr))
 
     def __del__(self):
@@ -237,24 +311,42 @@ class DeviceArray:
     def __repr__(self):
         return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, device={self.device}, ptr=0x{self.ptr or 0:x})"
 
+    def on(self, stream):
+        """The device pointer, for work about to be submitted on `stream`: records the stream on the
+        allocation and, if the array was last used on another stream, orders `stream` after that work."""
+        touch = getattr(self._alloc, "touch", None)
+        if touch is not None:
+            touch(stream)
+        return self.ptr
+
     # ---- transfers ----
     def copy_from_host(self, array):
         a = np.ascontiguousarray(array, dtype=self.dtype)
         if a.size != self.size:
             raise ValueError(f"size mismatch: host {a.size} vs device {self.size}")
-        lib = _ffi.lib()
-        _ffi.check(lib.ekm_h2d(self.device, self.ptr, a.ctypes.data, a.nbytes, current_stream()))
-        _ffi.check(lib.ekm_stream_sync(self.device, current_stream()))
+        lib, stream = _ffi.lib(), current_stream()
+        _ffi.check(lib.ekm_h2d(self.device, self.on(stream), a.ctypes.data, a.nbytes, stream))
+        _ffi.check(lib.ekm_stream_sync(self.device, stream))
         return self
 
-    def to_host(self, out=None):
+    def copy_from_host_async(self, array):
+        """Enqueue the upload on the current stream and return; `array` must stay alive and unchanged until
+        the stream has been synchronised (C-contiguous, same dtype and size)."""
+        if array.dtype != self.dtype or array.size != self.size or not array.flags.c_contiguous:
+            raise ValueError("copy_from_host_async: need a C-contiguous array of the same dtype and size")
+        stream = current_stream()
+        _ffi.check(_ffi.lib().ekm_h2d(self.device, self.on(stream), array.ctypes.data, array.nbytes, stream))
+        return self
+
+    def to_host(self, out=None, sync=True):
         if out is None:
             out = np.empty(self.shape, dtype=self.dtype)
         elif out.dtype != self.dtype or out.size != self.size or not out.flags.c_contiguous:
             raise ValueError("to_host(out=...): need a C-contiguous array of the same dtype and size")
-        lib = _ffi.lib()
-        _ffi.check(lib.ekm_d2h(self.device, out.ctypes.data, self.ptr, out.nbytes, current_stream()))
-        _ffi.check(lib.ekm_stream_sync(self.device, current_stream()))
+        lib, stream = _ffi.lib(), current_stream()
+        _ffi.check(lib.ekm_d2h(self.device, out.ctypes.data, self.on(stream), out.nbytes, stream))
+        if sync:
+            _ffi.check(lib.ekm_stream_sync(self.device, stream))
         return out
 
     def __array__(self, dtype=None, copy=None):
@@ -263,10 +355,21 @@ class DeviceArray:
 
     # ---- DLPack (zero-copy interop with other ROCm array libraries) ----
     def __dlpack__(self, stream=None):
+        """DLPack export.  `stream` is the CONSUMER's stream (array-API convention for ROCm: 0 = the default
+        stream, an integer > 2 = a hipStream_t, -1 = do not synchronise, None = unknown): the consumer's
+        stream is made to wait (on the device) for the work that produced this array; with None the host
+        waits instead, so that the data is complete for any stream."""
         from .dlpack import to_dlpack
 
-        lib = _ffi.lib()
-        _ffi.check(lib.ekm_stream_sync(self.device, current_stream()))  # the consumer may use any stream
+        last = getattr(self._alloc, "stream", None)
+        if stream is None:
+            _ffi.check(_ffi.lib().ekm_stream_sync(self.device, last))
+        elif stream != -1:
+            if not isinstance(stream, int) or stream in (1, 2) or stream < 0:
+                raise ValueError(f"__dlpack__: stream={stream!r} is not a valid ROCm stream (0, or a hipStream_t > 2)")
+            order_streams(self.device, last, stream or None)
+        if hasattr(self._alloc, "exported"):
+            self._alloc.exported = True
         return to_dlpack(self)
 
     def __dlpack_device__(self):

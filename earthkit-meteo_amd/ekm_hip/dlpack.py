@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-from .device import DeviceArray
+from .device import DeviceArray, current_stream, order_streams
 
 kDLROCM = 10
 kDLFloat = 2
@@ -84,14 +84,24 @@ def to_dlpack(arr):
 
 
 class _Borrowed:
-    """Keeps a consumed DLManagedTensor alive; runs the producer's deleter when the last view goes away."""
+    """Keeps a consumed DLManagedTensor alive; runs the producer's deleter when the last view goes away.
+    Tracks the stream the memory was last used on here, like an allocation of our own (device._Allocation)."""
 
-    def __init__(self, managed):
-        self.managed = managed
+    def __init__(self, managed, device, stream):
+        self.managed, self.device, self.stream = managed, device, stream
+
+    def touch(self, stream):
+        if stream != self.stream:
+            order_streams(self.device, self.stream, stream)
+            self.stream = stream
 
     def free(self):
         m, self.managed = self.managed, None
         if m is not None and m.deleter:
+            # the producer may reuse the memory as soon as its deleter has run: our work on it must be complete
+            from . import _ffi
+
+            _ffi.check(_ffi.lib().ekm_stream_sync(self.device, self.stream))
             m.deleter(C.pointer(m))
 
     def __del__(self):
@@ -102,8 +112,22 @@ class _Borrowed:
 
 
 def from_dlpack(obj):
-    """Wrap the memory of any object with `__dlpack__` (or a "dltensor" capsule) as a DeviceArray, zero-copy."""
-    cap = obj.__dlpack__() if hasattr(obj, "__dlpack__") else obj
+    """Wrap the memory of any object with `__dlpack__` (or a "dltensor" capsule) as a DeviceArray, zero-copy.
+
+    This is the way in for arrays of other ROCm libraries (the reference selects its backend from the
+    input type, `array_namespace(*inputs)`, thermo/array/thermo.py:826): `from_dlpack(torch_tensor)`.
+    The producer is handed OUR current stream (array-API `__dlpack__(stream=...)`: 0 = default stream on
+    ROCm), so it orders its pending work before anything we launch on that stream -- no host wait."""
+    stream = current_stream()
+    if hasattr(obj, "__dlpack__"):
+        if hasattr(obj, "__dlpack_device__") and obj.__dlpack_device__()[0] != kDLROCM:
+            raise TypeError(f"from_dlpack: device type {obj.__dlpack_device__()[0]} is not ROCm (kDLROCM = {kDLROCM})")
+        try:
+            cap = obj.__dlpack__(stream=stream or 0)
+        except TypeError:  # a producer without the stream argument
+            cap = obj.__dlpack__()
+    else:
+        cap = obj
     if not _api.PyCapsule_IsValid(cap, _NAME):
         raise TypeError("from_dlpack: expected an object with __dlpack__ or an unused 'dltensor' capsule")
     m = DLManagedTensor.from_address(_api.PyCapsule_GetPointer(cap, _NAME))
@@ -121,4 +145,5 @@ def from_dlpack(obj):
             expect *= shape[i]
     _api.PyCapsule_SetName(cap, _USED)  # we own the tensor now
     dtype = np.dtype(np.float32 if t.dtype.bits == 32 else np.float64)
-    return DeviceArray(_Borrowed(m), (t.data or 0) + int(t.byte_offset), shape, dtype, int(t.device.device_id))
+    dev = int(t.device.device_id)
+    return DeviceArray(_Borrowed(m, dev, stream), (t.data or 0) + int(t.byte_offset), shape, dtype, dev)

@@ -99,20 +99,8 @@ def pressure_on_hybrid_levels(A, B, sp, levels=None, alpha_top="ifs", output="fu
     d_rf = _dev_bytes(row_full, device) if row_full is not None else None
     d_rh = _dev_bytes(row_half, device) if row_half is not None else None
 
-    # the reference's global any(p_half[0] <= 0.1) (vertical.py:680, 694)
-    a0, b0 = float(A[0]), float(B[0])
-    if b0 == 0.0 or npts == 0:
-        top_is_zero = bool(a0 <= PRESSURE_TOA)
-    elif not on_device:
-        top_is_zero = bool(np.any(A[0].astype(dtype) + B[0].astype(dtype) * np.asarray(sp, dtype=dtype) <= PRESSURE_TOA))
-    else:
-        flag = _dev_bytes(np.zeros(1, np.int32), device)
-        _ffi.check(getattr(lib, f"ekm_any_le_{tag}")(device, stream, d_sp.ptr, npts, real(a0), real(b0),
-                                                     real(PRESSURE_TOA), flag.ptr))
-        host = np.zeros(1, np.int32)
-        _ffi.check(lib.ekm_d2h(device, host.ctypes.data, flag.ptr, 4, stream))
-        _ffi.check(lib.ekm_stream_sync(device, stream))
-        top_is_zero = bool(host[0])
+    d_sp.on(stream)  # an `sp` last used on another stream: order this stream after that work
+    top_is_zero = _top_is_zero(A[0], B[0], sp, d_sp, dtype, npts, device, on_device)
     a_top = float(np.log(2)) if alpha_top == "ifs" else 1.0
 
     bufs = {}
@@ -211,6 +199,9 @@ def _chain(t, q, zs, A, B, sp, alpha_top, mode, vertical_axis):
         return DeviceArray.from_host(np.ascontiguousarray(np.asarray(v), dtype=dtype), device)
 
     d = {k: (dev(v) if v is not None else None) for k, v in host.items()}
+    for v in d.values():
+        if v is not None:
+            v.on(current_stream())  # inputs last used on another stream: order this stream after that work
     d_a, d_b = dev(A), dev(B)
     top = _top_is_zero(A[0], B[0], host["sp"], d["sp"], dtype, npts, device, isinstance(host["sp"], DeviceArray))
     a_top = float(np.log(2)) if alpha_top == "ifs" else 1.0

@@ -18,14 +18,6 @@ CASES = manifest()
 
 
 @pytest.fixture(scope="module")
-def ek():
-    import ekm_hip
-
-    assert ekm_hip.device_count() >= 1
-    return ekm_hip
-
-
-@pytest.fixture(scope="module")
 def orc():
     from oracle import thermo_oracle
 
@@ -552,7 +544,7 @@ def test_device_array_api(ek):
     ek.empty_cache()
 
 
-def test_entry_points_are_graph_capturable():
+def test_entry_points_are_graph_capturable(ek):
     """tests/native/graph_capture.cpp: two thermo launches recorded into a hipGraph, replayed three times on
     new inputs, bit-identical to direct launches (the C ABI's 'no allocation, no copy, no sync' convention)."""
     import os

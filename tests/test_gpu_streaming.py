@@ -1,0 +1,171 @@
+"""Host-side data movement on a real MI355X: the streamed NumPy path (bounded device working set, prefault,
+lanes), cross-stream ordering, the block cache, and DLPack exchange with a FOREIGN ROCm library (torch is
+used here -- in the tests only -- as that foreign producer / consumer; the product never imports it)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+np.seterr(all="ignore")
+
+
+def _fields(nlev, npts, dtype=np.float32, seed=5):
+    from oracle import synthetic
+
+    t, q, p, _ = synthetic.make_fields(nlev, npts, dtype=dtype, seed=seed)
+    return t, q, p
+
+
+def _device_path(ek, func, arrays, **kw):
+    d = [ek.to_device(a) for a in arrays]
+    out = getattr(ek.thermo, func)(*d, **kw)
+    out = out if isinstance(out, tuple) else (out,)
+    return [o.to_host() for o in out]
+
+
+def test_large_multi_output_numpy_call_is_bit_equal_to_the_device_path(ek):
+    """>= 256 MB of NumPy input takes the streamed path (slices on lane streams, result pages prefaulted by a
+    helper thread while data is in flight).  The prefault must never alter data that has already landed:
+    every one of the six outputs must equal the DeviceArray path bit for bit."""
+    t, q, p = _fields(16, 1 << 21)  # 3 x 128 MiB in, 6 x 128 MiB out
+    assert t.nbytes * 3 >= 256 << 20
+    want = _device_path(ek, "pipeline_full", (t, q, p))
+    for rep in range(3):
+        got = ek.thermo.pipeline_full(t, q, p)
+        for k, (g, w) in enumerate(zip(got, want)):
+            assert g.dtype == w.dtype and g.shape == w.shape
+            assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), f"rep {rep} output {k} differs"
+
+
+def test_streaming_stays_within_a_capped_device_budget(ek, monkeypatch):
+    """fields whose working set exceeds the device budget stream through in slices, two or
+    more in flight, device blocks recycled between slices.  Budget capped at 96 MiB against a 768 MiB
+    working set; the peak of live device bytes must stay under the cap and the result must be unchanged."""
+    from ekm_hip import _engine
+
+    t, q, p = _fields(64, 1 << 19)  # 3 x 128 MiB in, 3 x 128 MiB out = 768 MiB working set
+    want = _device_path(ek, "pipeline_svp_td_rh", (t, q, p))
+    cap = 96 << 20
+    monkeypatch.setenv("EKM_STREAM_BUDGET_BYTES", str(cap))
+    ek.empty_cache()
+    ek.memory_stats(reset_peak=True)
+    base = ek.memory_stats()["live_bytes"]
+    lanes, nslices = _engine.plan_slices(64, 6 * (1 << 19) * 4, cap)
+    assert lanes >= 2 and nslices > lanes  # more slices than lanes: blocks are recycled
+    got = ek.thermo.pipeline_svp_td_rh(t, q, p)
+    peak = ek.memory_stats()["peak_live_bytes"] - base
+    print(f"streaming: lanes={lanes} slices={nslices} peak live {peak / 2**20:.1f} MiB of cap {cap / 2**20:.0f} MiB")
+    assert 0 < peak <= cap, (peak, cap)
+    for g, w in zip(got, want):
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+    # a budget that cannot hold two single-row slices is an error, not an OOM
+    monkeypatch.setenv("EKM_STREAM_BUDGET_BYTES", str(1 << 20))
+    with pytest.raises(ek.EkmError, match="streaming budget"):
+        ek.thermo.pipeline_svp_td_rh(t, q, p)
+
+
+def test_level_vector_operand_is_sliced_with_the_fields(ek):
+    t, q, p = _fields(32, 1 << 20)
+    plev = np.ascontiguousarray(p[:, :1])  # (32, 1): one pressure per level
+    pfull = np.ascontiguousarray(np.broadcast_to(plev, t.shape))
+    want = _device_path(ek, "potential_temperature", (t, pfull))[0]
+    got = ek.thermo.potential_temperature(t, plev)  # 2 x 128 MiB... t alone is 128 MiB: force the streamed path
+    from ekm_hip import _engine
+
+    got2 = _engine._run_streamed("potential_temperature", (t, plev), (), None, None, [ek.current_device()])[0]
+    assert np.array_equal(got, want) and np.array_equal(got2, want)
+
+
+def test_float16_and_dtype_override_do_not_depend_on_size(ek):
+    """the result dtype of float16 input must not depend on which path the size selects."""
+    small = np.linspace(250, 300, 1000).astype(np.float16)
+    big = np.resize(small, 6 << 20)  # 12 MiB fp16 -> 24 MiB fp32 result: the pretouch path
+    for a in (small, big):
+        out = ek.thermo.saturation_vapour_pressure(a)
+        assert out.dtype == np.float16, (a.size, out.dtype)
+    from ekm_hip import _engine
+
+    t, q, p = _fields(8, 1 << 16)
+    o = _engine._run_streamed("potential_temperature", (t, p), (), None, np.float64, [ek.current_device()])[0]
+    assert o.dtype == np.float64
+
+
+def test_cross_stream_consumer_waits_for_the_producer(ek):
+    """An array produced on one non-blocking stream and consumed on another is ordered on the device
+    (DeviceArray.on -> order_streams); results must equal the single-stream chain."""
+    t, q, p = _fields(8, 1 << 20)
+    want = _device_path(ek, "potential_temperature", (_device_path(ek, "dewpoint_from_specific_humidity", (q, p))[0], p))[0]
+    s1, s2 = ek.stream_create(), ek.stream_create()
+    try:
+        for rep in range(5):
+            ek.set_stream(s1)
+            dq, dp = ek.to_device(q), ek.to_device(p)
+            td = ek.thermo.dewpoint_from_specific_humidity(dq, dp)       # produced on s1 (asynchronous)
+            ek.set_stream(s2)
+            th = ek.thermo.potential_temperature(td, dp)                 # consumed on s2: must wait for s1
+            got = th.to_host()
+            assert np.array_equal(got, want), f"rep {rep}"
+            del td, th, dq, dp   # blocks go back under the stream they were last used on
+    finally:
+        ek.set_stream(None)
+        ek.synchronize()
+        ek.stream_destroy(s1)
+        ek.stream_destroy(s2)
+
+
+def test_lane_streams_are_bounded_and_releasable(ek):
+    from ekm_hip import _engine
+
+    t, q, p = _fields(24, 1 << 18)
+    for rows in (24, 17, 9):  # different leading-axis lengths must not create new streams per length
+        _engine._run_streamed("potential_temperature", (t[:rows], p[:rows]), (), None, None, [ek.current_device()])
+    assert 0 < len(_engine._streams) <= _engine._MAX_LANES
+    ek.release_streams()
+    assert len(_engine._streams) == 0
+    out = ek.thermo.potential_temperature(t, p)  # still works afterwards (streams are re-created on demand)
+    assert np.isfinite(out).all()
+
+
+# ---- DLPack with a foreign ROCm library -----------------------------------------------------------------
+@pytest.fixture(scope="module")
+def torch_rocm(ek):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no ROCm device")
+    return torch
+
+
+def test_dlpack_foreign_producer_and_consumer_zero_copy(ek, torch_rocm):
+    """torch tensor -> ek.from_dlpack (zero copy) -> HIP kernel -> torch.from_dlpack(result) (zero copy), with the
+    stream hand-over of the array-API protocol in both directions.  This is the route the reference's
+    `array_namespace(*inputs)` dispatch (thermo/array/thermo.py:826) offers to Torch users."""
+    torch = torch_rocm
+    t, q, p = _fields(4, 1 << 20)
+    want = _device_path(ek, "relative_humidity_from_specific_humidity", (t, q, p))[0]
+    dev = torch.device("cuda", ek.current_device())
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):  # producer work on a non-default torch stream, still in flight at hand-over
+        tt = torch.from_numpy(t).to(dev, non_blocking=False) * 1.0
+        tq = torch.from_numpy(q).to(dev) * 1.0
+        tp = torch.from_numpy(p).to(dev) * 1.0
+        dt_, dq_, dp_ = (ek.from_dlpack(x) for x in (tt, tq, tp))
+    assert dt_.ptr == tt.data_ptr() and dq_.ptr == tq.data_ptr()  # zero copy in
+    assert dt_.shape == t.shape and dt_.dtype == np.float32
+    rh = ek.thermo.relative_humidity_from_specific_humidity(dt_, dq_, dp_)
+    back = torch.from_dlpack(rh)  # consumer passes ITS current stream: ordered after our kernel
+    assert back.data_ptr() == rh.ptr and tuple(back.shape) == t.shape  # zero copy out
+    doubled = (back * 2.0).cpu().numpy()
+    assert np.array_equal(doubled, want * 2.0)
+    assert np.array_equal(back.cpu().numpy(), want)
+    del back, rh, dt_, dq_, dp_
+
+
+def test_dlpack_rejects_non_rocm_and_non_float(ek, torch_rocm):
+    torch = torch_rocm
+    with pytest.raises(TypeError):
+        ek.from_dlpack(torch.ones(4))  # CPU tensor
+    with pytest.raises(TypeError):
+        ek.from_dlpack(torch.ones(4, dtype=torch.int32, device="cuda"))
+    with pytest.raises(ValueError):
+        ek.from_dlpack(torch.ones(4, 4, device="cuda").t())  # not C-contiguous

@@ -10,15 +10,6 @@ from test_vertical_oracle import CASES, G, case_args
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ek():
-    import ekm_hip
-    import ekm_hip.vertical  # noqa: F401
-
-    assert ekm_hip.device_count() >= 1
-    return ekm_hip
-
-
 def _close(got, want, name, f32):
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     assert got.shape == want.shape, (name, got.shape, want.shape)

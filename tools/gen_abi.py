@@ -175,7 +175,7 @@ EKM_API int ekm_malloc(int dev, size_t bytes, void** out);
 EKM_API int ekm_free(int dev, void* ptr);
 EKM_API int ekm_host_alloc(size_t bytes, void** out);  /* pinned host memory for fast transfers */
 EKM_API int ekm_host_free(void* ptr);
-EKM_API int ekm_host_prefault(void* ptr, size_t bytes, int nthreads); /* touch every page of a fresh host buffer */
+EKM_API int ekm_host_prefault(void* ptr, size_t bytes, int nthreads); /* fault in every page of a host buffer; never changes its contents */
 EKM_API int ekm_h2d(int dev, void* dst, const void* src, size_t bytes, void* stream);
 EKM_API int ekm_d2h(int dev, void* dst, const void* src, size_t bytes, void* stream);
 EKM_API int ekm_d2d(int dev, void* dst, const void* src, size_t bytes, void* stream);
@@ -187,6 +187,7 @@ EKM_API int ekm_stream_sync(int dev, void* stream);
 EKM_API int ekm_event_create(int dev, void** out);
 EKM_API int ekm_event_destroy(int dev, void* event);
 EKM_API int ekm_event_record(int dev, void* event, void* stream);
+EKM_API int ekm_stream_wait_event(int dev, void* stream, void* event); /* later work on `stream` waits for `event` (no host wait) */
 EKM_API int ekm_event_sync(int dev, void* event);
 EKM_API int ekm_event_elapsed_ms(int dev, void* start, void* stop, float* ms);
 
