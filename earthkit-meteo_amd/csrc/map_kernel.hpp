@@ -11,9 +11,11 @@
 //    grid-stride loop: in-order dispatch keeps one moving window per stream,
 //    measured 10-25 % faster), UNROLL tiles in flight per lane per trip;
 //  * operands that are not full fields (a scalar, or a level vector such as the
-//    137 model-level pressures) never touch HBM per point: the vector is staged
-//    once per workgroup into LDS and indexed by level, with the level index
-//    advanced incrementally (no per-point integer division).
+//    137 model-level pressures) never touch HBM per point.  The usual shape --
+//    fields + ONE such operand last (pressure) -- runs on a 2-D grid (horizontal
+//    tile x level), so the pressure of a workgroup's level is a wave-uniform value
+//    (map_levels); any other mix stages the vectors once per workgroup in LDS and
+//    indexes them by a level counter advanced incrementally (map_bcast).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -95,6 +97,21 @@ __device__ __forceinline__ void st_stream(T* p, typename VecOf<T>::type v) {
 #endif
 }
 
+// Ops with a per-workgroup LDS table (OpTable<Op>::elems > 0, ops.hpp): reserve it, fill it once, pass it on.
+template <class Op, class T>
+__device__ __forceinline__ void op_apply(const T* __restrict__ x, T* __restrict__ y, T rp, const T* __restrict__ tab) {
+  if constexpr (OpTable<Op>::elems > 0)
+    OpTable<Op>::template apply<T>(x, y, rp, tab);
+  else
+    Op::template apply<T>(x, y, rp);
+}
+#define EKM_OP_TABLE(Op, T, name)                                              \
+  __shared__ T name[OpTable<Op>::elems > 0 ? OpTable<Op>::elems : 1];          \
+  if constexpr (OpTable<Op>::elems > 0) {                                      \
+    OpTable<Op>::template fill<T>(name, (int)threadIdx.x, kThreads);           \
+    __syncthreads();                                                           \
+  }
+
 // ---- all operands are aligned full fields ----------------------------------
 // Workgroup b owns `tiles` consecutive tiles of 256 vectors (256 x 16 B = 4 KiB per
 // stream per tile) and exits: the dispatcher hands out workgroups in order, so at any
@@ -104,6 +121,7 @@ template <class Op, class T, int UNROLL>
 __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_fields(const MapArgs<T, Op::NIN, Op::NOUT> a, unsigned tiles) {
   constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N;
   typedef typename VecOf<T>::type Vec;
+  EKM_OP_TABLE(Op, T, op_tab)
   const unsigned long long nvec = a.n / V;
   const unsigned long long base = (unsigned long long)blockIdx.x * tiles * kThreads + threadIdx.x;
 
@@ -128,7 +146,7 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_fields(const M
           T x[NIN], y[NOUT];
 #pragma unroll
           for (int i = 0; i < NIN; ++i) x[i] = xin[u][i][j];
-          Op::template apply<T>(x, y, a.rp);
+          op_apply<Op, T>(x, y, a.rp, op_tab);
 #pragma unroll
           for (int o = 0; o < NOUT; ++o) yout[o][j] = y[o];
 #if EKM_SCHED_SPLIT
@@ -146,7 +164,7 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_fields(const M
     T x[NIN], y[NOUT];
 #pragma unroll
     for (int i = 0; i < NIN; ++i) x[i] = a.in[i][e];
-    Op::template apply<T>(x, y, a.rp);
+    op_apply<Op, T>(x, y, a.rp, op_tab);
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) a.out[o][e] = y[o];
   }
@@ -160,6 +178,7 @@ __global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, 
   constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N;
   typedef typename VecOf<T>::type Vec;
   T* lds = reinterpret_cast<T*>(ekm_lds_raw);
+  EKM_OP_TABLE(Op, T, op_tab)
 
   // stage the shared vectors once per workgroup
   T sval[NIN];
@@ -244,7 +263,7 @@ __global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, 
         T x[NIN], y[NOUT];
 #pragma unroll
         for (int i = 0; i < NIN; ++i) x[i] = xin[i][j];
-        Op::template apply<T>(x, y, a.rp);
+        op_apply<Op, T>(x, y, a.rp, op_tab);
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) yout[o][j] = y[o];
       }
@@ -277,145 +296,126 @@ __global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, 
   }
 }
 
-// ---- the usual broadcast shape: last operand (pressure) is a level vector or a scalar ----
-// Fields are streamed exactly as in map_fields; the level vector sits in LDS and a lane's
-// 16-B chunk almost always lies inside one level, so the pressure of the chunk is ONE
-// value: every sub-expression that depends on pressure alone (log2(p/p0), (p0/p)^kappa,
-// (p/p0)^kappa, 1/D(p), ...) is then computed once per chunk instead of once per point
-// (the compiler hoists it out of the unrolled per-point bodies), and p costs no HBM traffic.
-#ifndef EKM_LEVEL_LDS
-#define EKM_LEVEL_LDS 1
-#endif
+// ---- the usual broadcast shape: fields + pressure given per level (vector / scalar / hybrid definition) ----
+// 3-D grid: blockIdx.x walks the horizontal tiles of ONE level inside a band of `gridDim.x` tiles (in order, so
+// every stream is still one moving window), blockIdx.y selects the level (group), blockIdx.z the band.  The
+// dispatcher issues x fastest, then y, then z: all levels of a band are processed before the next band starts.
+// PM_LEVEL uses one band (the whole level); PM_HYBRID uses bands of 4 MiB of surface pressure, so that the
+// band's sp chunk is still in the XCD's L2 when the next level re-reads it (each XCD sees every 8th tile:
+// 512 KiB of sp per band against 4 MiB of L2), instead of coming back from the Infinity Cache / HBM once per
+// level (26 MB x 137 levels: measured 1.10x the algorithmic traffic in round 1).
+// Everything that depends on the level alone is wave-uniform:
+//  * PM_LEVEL: the pressure of the level is one scalar load; sub-expressions of pressure alone (log2(p/p0),
+//    (p0/p)^kappa, (p/p0)^kappa, 1/D(p), ...) are computed once per 16-B chunk instead of once per point, and
+//    p costs no HBM traffic.  A scalar operand is the one-level case.
+//  * PM_HYBRID (EKM_HYBRID_FULL): p = ph_k + 0.5*(ph_k+1 - ph_k), ph_h = A_h + B_h*sp (vertical.py:670,708) from
+//    the lane's surface-pressure chunk; the pressure field itself never exists.  (A workgroup can also walk
+//    `lev_per_wg` > 1 consecutive levels of its tile with sp and ph_k+1 kept in registers; measured slower
+//    than 1 because every stream then has lev_per_wg windows open: profiles/r02_sweep_hybrid.txt.)
+// No per-lane position bookkeeping, no integer division, no LDS: a tile never straddles levels.
+enum { PM_LEVEL = 0, PM_HYBRID = 1 };
 
-template <class Op, class T>
-__global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_plast(const MapArgs<T, Op::NIN, Op::NOUT> a,
-                                                                      unsigned tiles) {
+template <class T, int NIN, int NOUT>
+struct LevArgs {
+  const T* in[NIN];  // fields; in[NIN-1] = the level vector (PM_LEVEL) or the surface pressure (PM_HYBRID)
+  T* out[NOUT];
+  const T* A;        // PM_HYBRID: half-level tables, last + 2 values each
+  const T* B;
+  unsigned long long n;  // grid points
+  unsigned inner;        // points per level (< 2^31)
+  unsigned nlev;         // levels covered by n points = ceil(n / inner)
+  unsigned last;         // highest valid index of the level vector / full-level index
+  unsigned lev_per_wg;   // consecutive levels one workgroup walks (PM_LEVEL: 1)
+  unsigned tiles;        // consecutive horizontal tiles per workgroup
+  T rp;
+};
+
+template <class Op, class T, int PMODE, bool ALIGNED>
+__global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_levels(const LevArgs<T, Op::NIN, Op::NOUT> a) {
   constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N, PI = Op::NIN - 1;
   typedef typename VecOf<T>::type Vec;
-  const int mode = a.mode[PI];
-  const bool lev = mode == EKM_LEVEL_MAJOR, hyb = mode == EKM_HYBRID_FULL;
-  const unsigned long long inner = a.inner[PI];
-  T* lds = reinterpret_cast<T*>(ekm_lds_raw);
-#if EKM_LEVEL_LDS
-  const T* tab = lds;
-  if (lev) {
-    for (unsigned s = threadIdx.x; s < a.len[PI]; s += kThreads) lds[s] = a.in[PI][s];
-    __syncthreads();
-  }
-#else
-  const T* tab = a.in[PI];
-#endif
-  const unsigned nhalf = a.len[PI] + 1;
-  if (hyb) {  // A then B half-level tables in LDS
-    for (unsigned s = threadIdx.x; s < nhalf; s += kThreads) {
-      lds[s] = a.aux0[s];
-      lds[nhalf + s] = a.aux1[s];
-    }
-    __syncthreads();
-  }
-  const T sval = (lev || hyb) ? T(0) : a.in[PI][0];
-  const unsigned last = (lev || hyb) ? a.len[PI] - 1 : 0;
-  // pressure of full level l at surface pressure s (vertical.py:670, 708)
-  auto hybrid_p = [&](unsigned long long l, T s) {
-    const T ph0 = lds[l] + lds[nhalf + l] * s;
-    const T ph1 = lds[l + 1] + lds[nhalf + l + 1] * s;
-    return ph0 + T(0.5) * (ph1 - ph0);
-  };
+  EKM_OP_TABLE(Op, T, op_tab)
+  const unsigned k0 = blockIdx.y * a.lev_per_wg;  // wave-uniform
 
-  const unsigned long long nvec = a.n / V;
-  const unsigned long long cblock = (unsigned long long)blockIdx.x * tiles * kThreads;  // wave-uniform
-  unsigned long long q = 0, r = 0;
-  if (lev || hyb) {  // one division per workgroup on the scalar unit, then carried forward per tile
-    const unsigned long long e = cblock * V;
-    q = e / inner;
-    r = e % inner + (unsigned long long)threadIdx.x * V;
-    while (r >= inner) {
-      r -= inner;
-      q += 1;
-    }
-  }
+  for (unsigned i = 0; i < a.tiles; ++i) {
+    const unsigned long long tile = (unsigned long long)blockIdx.z * gridDim.x + blockIdx.x;
+    const unsigned long long col64 = (tile * a.tiles + i) * (kThreads * V) + threadIdx.x * V;
+    if (col64 >= a.inner) continue;
+    const unsigned col = (unsigned)col64;
 
-  for (unsigned k = 0; k < tiles; ++k) {
-    const unsigned long long v = cblock + (unsigned long long)k * kThreads + threadIdx.x;
-    if (v < nvec) {
-      Vec xin[NIN], yout[NOUT];
+    T ph0[V], s[V];  // PM_HYBRID: lower half-level pressure carried up the column, surface pressure
+    if (PMODE == PM_HYBRID) {
+      const T* sp = a.in[PI];
+      if (ALIGNED && col + V <= a.inner) {
+        const Vec sv = *reinterpret_cast<const Vec*>(sp + col);  // cached load: other level groups re-read it
 #pragma unroll
-      for (int i = 0; i < PI; ++i) xin[i] = ld_stream<T>(a.in[i] + v * V);
-      if (hyb) {
-        const T* sp = a.in[PI];
-        if (r + V <= inner && (r % V) == 0 && a.vec_ok) {  // aligned chunk inside one level
-          const Vec s = *reinterpret_cast<const Vec*>(sp + r);  // cached load: sp is re-read per level
+        for (int j = 0; j < V; ++j) s[j] = sv[j];
+      } else {
 #pragma unroll
-          for (int j = 0; j < V; ++j) xin[PI][j] = hybrid_p(q, s[j]);
-        } else {
+        for (int j = 0; j < V; ++j) s[j] = (col + j < a.inner) ? sp[col + j] : T(1);
+      }
+      const unsigned kk = k0 <= a.last ? k0 : a.last;
+      const T a0 = a.A[kk], b0 = a.B[kk];
 #pragma unroll
-          for (int j = 0; j < V; ++j) {
-            unsigned long long l = q, rr = r + j;
-            if (rr >= inner) {
-              rr -= inner;
-              l = l + 1 <= last ? l + 1 : last;
-            }
-            xin[PI][j] = hybrid_p(l, sp[rr]);
+      for (int j = 0; j < V; ++j) ph0[j] = a0 + b0 * s[j];
+    }
+
+    for (unsigned l = 0; l < a.lev_per_wg; ++l) {
+      const unsigned k = k0 + l;
+      if (k >= a.nlev) break;
+      const unsigned kk = k <= a.last ? k : a.last;
+      const unsigned long long row = (unsigned long long)k * a.inner;
+      const unsigned long long left = a.n - row;  // the last covered level may be partial
+      const unsigned rowlen = left < a.inner ? (unsigned)left : a.inner;
+      if (col >= rowlen) break;
+      const unsigned long long e0 = row + col;
+
+      T pv[V];
+      if (PMODE == PM_HYBRID) {
+        const T a1 = a.A[kk + 1], b1 = a.B[kk + 1];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const T ph1 = a1 + b1 * s[j];
+          pv[j] = ph0[j] + T(0.5) * (ph1 - ph0[j]);
+          ph0[j] = ph1;
+        }
+      } else {
+        const T pl = a.in[PI][kk];
+#pragma unroll
+        for (int j = 0; j < V; ++j) pv[j] = pl;
+      }
+
+      if (ALIGNED && col + V <= rowlen) {
+        Vec xin[NIN > 1 ? NIN - 1 : 1], yout[NOUT];
+#pragma unroll
+        for (int f = 0; f < PI; ++f) xin[f] = ld_stream<T>(a.in[f] + e0);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          T x[NIN], y[NOUT];
+#pragma unroll
+          for (int f = 0; f < PI; ++f) x[f] = xin[f][j];
+          x[PI] = pv[j];
+          op_apply<Op, T>(x, y, a.rp, op_tab);
+#pragma unroll
+          for (int o = 0; o < NOUT; ++o) yout[o][j] = y[o];
+        }
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) st_stream<T>(a.out[o] + e0, yout[o]);
+      } else {  // unaligned rows / ragged end of a row: element by element
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          if (col + j < rowlen) {
+            T x[NIN], y[NOUT];
+#pragma unroll
+            for (int f = 0; f < PI; ++f) x[f] = a.in[f][e0 + j];
+            x[PI] = pv[j];
+            op_apply<Op, T>(x, y, a.rp, op_tab);
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) a.out[o][e0 + j] = y[o];
           }
         }
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-          T x[NIN], y[NOUT];
-#pragma unroll
-          for (int i = 0; i < NIN; ++i) x[i] = xin[i][j];
-          Op::template apply<T>(x, y, a.rp);
-#pragma unroll
-          for (int o = 0; o < NOUT; ++o) yout[o][j] = y[o];
-        }
-      } else if (!lev || r + V <= inner) {  // the whole chunk has one pressure
-        const T pv = lev ? tab[q] : sval;
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-          T x[NIN], y[NOUT];
-#pragma unroll
-          for (int i = 0; i < PI; ++i) x[i] = xin[i][j];
-          x[PI] = pv;
-          Op::template apply<T>(x, y, a.rp);
-#pragma unroll
-          for (int o = 0; o < NOUT; ++o) yout[o][j] = y[o];
-        }
-      } else {  // the chunk straddles a level boundary (inner >= V: at most one)
-        const T pv0 = tab[q], pv1 = tab[q + 1 <= last ? q + 1 : last];
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-          T x[NIN], y[NOUT];
-#pragma unroll
-          for (int i = 0; i < PI; ++i) x[i] = xin[i][j];
-          x[PI] = (r + j < inner) ? pv0 : pv1;
-          Op::template apply<T>(x, y, a.rp);
-#pragma unroll
-          for (int o = 0; o < NOUT; ++o) yout[o][j] = y[o];
-        }
-      }
-#pragma unroll
-      for (int o = 0; o < NOUT; ++o) st_stream<T>(a.out[o] + v * V, yout[o]);
-    }
-    if (lev || hyb) {
-      q += a.step_q[PI];
-      r += a.step_r[PI];
-      if (r >= inner) {
-        r -= inner;
-        q += 1;
       }
     }
-  }
-  // ragged tail: n % V single elements, done by the first lanes of workgroup 0
-  const unsigned long long e = nvec * V + (unsigned long long)blockIdx.x * kThreads + threadIdx.x;
-  if (e < a.n) {
-    T x[NIN], y[NOUT];
-#pragma unroll
-    for (int i = 0; i < PI; ++i) x[i] = a.in[i][e];
-    unsigned long long l = (lev || hyb) ? e / inner : 0;
-    if (l > last) l = last;
-    x[PI] = hyb ? hybrid_p(l, a.in[PI][e % inner]) : (lev ? tab[l] : sval);
-    Op::template apply<T>(x, y, a.rp);
-#pragma unroll
-    for (int o = 0; o < NOUT; ++o) a.out[o][e] = y[o];
   }
 }
 
@@ -425,6 +425,9 @@ int device_cus(int dev);            // CU count of device `dev` (cached), <0 on 
 int use_device(int dev);            // hipSetDevice with error capture
 int tuning_tiles_per_block();
 int tuning_unroll();
+int tuning_lev_per_wg();    // EKM_HYBRID_FULL: consecutive levels one workgroup walks (EKM_LEV_PER_WG, default 1)
+int tuning_hybrid_band_bytes();  // EKM_HYBRID_FULL: bytes of surface pressure per band (EKM_HYBRID_BAND_KB, default 4096 KiB)
+int tuning_table_tiles();   // tiles per workgroup for ops that build an LDS table (EKM_TABLE_TILES, default 16)
 
 constexpr unsigned kMaxLdsBytes = 64 * 1024;
 
@@ -492,7 +495,6 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
         a.inner[i] = op->inner;
         a.aux0 = static_cast<const T*>(op->aux0);
         a.aux1 = static_cast<const T*>(op->aux1);
-        lds_elems += 2 * ((a.len[i] + 1 + 3u) & ~3u);
         break;
       }
       default:
@@ -512,6 +514,8 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
   const unsigned long long nchunk = (n + V - 1) / V;
   const unsigned long long ntile = (nchunk + kThreads - 1) / kThreads;
   unsigned tiles = (unsigned)tuning_tiles_per_block();
+  // an op that builds an LDS table per workgroup amortises it over more tiles (bisection: 4096 es values)
+  if (OpTable<Op>::elems > 0 && tiles < (unsigned)tuning_table_tiles()) tiles = (unsigned)tuning_table_tiles();
   const int unroll = tuning_unroll();
   if (!bc && aligned && unroll >= 2) tiles = (tiles + 1u) & ~1u;  // the unrolled body takes tiles in pairs
   // keep the grid within the launch limit for very large fields
@@ -519,21 +523,68 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
   const unsigned grid = (unsigned)((ntile + tiles - 1) / tiles);
   hipStream_t s = static_cast<hipStream_t>(stream);
 
-  bool plast = false;  // all fields aligned, only the last operand a level vector / scalar
+  // fields + one per-level operand last (pressure as a level vector, a scalar or the hybrid definition)
+  bool levels = false;
   if constexpr (NIN >= 2) {
-    plast = bc && aligned && (a.mode[NIN - 1] == EKM_LEVEL_MAJOR || a.mode[NIN - 1] == EKM_SCALAR ||
-                              a.mode[NIN - 1] == EKM_HYBRID_FULL);
-    for (int i = 0; i + 1 < NIN; ++i) plast = plast && a.mode[i] == EKM_FIELD;
-  }
-  if (plast) {
-    const unsigned long long step = (unsigned long long)kThreads * V;
-    if (a.mode[NIN - 1] == EKM_LEVEL_MAJOR || a.mode[NIN - 1] == EKM_HYBRID_FULL) {
-      a.step_q[NIN - 1] = step / a.inner[NIN - 1];
-      a.step_r[NIN - 1] = step % a.inner[NIN - 1];
+    const int pm = a.mode[NIN - 1];
+    levels = bc && (pm == EKM_LEVEL_MAJOR || pm == EKM_SCALAR || pm == EKM_HYBRID_FULL);
+    for (int i = 0; i + 1 < NIN; ++i) levels = levels && a.mode[i] == EKM_FIELD;
+    if (levels) {
+      LevArgs<T, NIN, NOUT> la;
+      for (int i = 0; i < NIN; ++i) la.in[i] = a.in[i];
+      for (int o = 0; o < NOUT; ++o) la.out[o] = a.out[o];
+      la.A = a.aux0;
+      la.B = a.aux1;
+      la.n = n;
+      la.rp = a.rp;
+      unsigned long long inner = a.inner[NIN - 1];
+      la.last = pm == EKM_SCALAR ? 0u : a.len[NIN - 1] - 1u;
+      if (pm == EKM_SCALAR) inner = n < (1ull << 30) ? n : (1ull << 30);  // one "level" of any convenient length
+      const unsigned long long nlev = (n + inner - 1) / inner;
+      la.lev_per_wg = pm == EKM_HYBRID_FULL ? (unsigned)tuning_lev_per_wg() : 1u;
+      if (la.lev_per_wg > nlev) la.lev_per_wg = (unsigned)nlev;
+      const unsigned long long gy = (nlev + la.lev_per_wg - 1) / la.lev_per_wg;
+      // shapes this kernel is not meant for go to map_bcast: rows longer than 32-bit columns, more level
+      // groups than gridDim.y allows, or rows much shorter than a workgroup (a vector along a short axis)
+      const bool fits = inner < (1ull << 31) && gy <= 65535ull && (inner >= (unsigned long long)kThreads || pm == EKM_HYBRID_FULL);
+      if (!fits && pm == EKM_HYBRID_FULL)
+        return set_error(EKM_ERR_ARG, "EKM_HYBRID_FULL: inner = %llu, len = %u is outside the supported range", inner,
+                         a.len[NIN - 1]);
+      levels = fits;
+      if (levels) {
+        la.inner = (unsigned)inner;
+        la.nlev = (unsigned)nlev;
+        la.tiles = OpTable<Op>::elems > 0 ? tiles : 1u;
+        const unsigned long long per_wg = (unsigned long long)kThreads * V * la.tiles;
+        const unsigned long long ntx = (inner + per_wg - 1) / per_wg;  // workgroups along one level
+        // hybrid: bands of EKM_HYBRID_BAND_KB of surface pressure (L2-resident between levels); else one band
+        unsigned long long band = ntx;
+        if (pm == EKM_HYBRID_FULL) {
+          band = (unsigned long long)tuning_hybrid_band_bytes() / (per_wg * sizeof(T));
+          if (band < 8) band = 8;
+          if (band > ntx) band = ntx;
+          while ((ntx + band - 1) / band > 65535ull) band *= 2;
+        }
+        const dim3 g((unsigned)band, (unsigned)gy, (unsigned)((ntx + band - 1) / band));
+        const bool al = aligned && inner % V == 0;
+        if (pm == EKM_HYBRID_FULL) {
+          if (al)
+            hipLaunchKernelGGL((map_levels<Op, T, PM_HYBRID, true>), g, dim3(kThreads), 0, s, la);
+          else
+            hipLaunchKernelGGL((map_levels<Op, T, PM_HYBRID, false>), g, dim3(kThreads), 0, s, la);
+        } else {
+          if (al)
+            hipLaunchKernelGGL((map_levels<Op, T, PM_LEVEL, true>), g, dim3(kThreads), 0, s, la);
+          else
+            hipLaunchKernelGGL((map_levels<Op, T, PM_LEVEL, false>), g, dim3(kThreads), 0, s, la);
+        }
+      }
     }
-    hipLaunchKernelGGL((map_plast<Op, T>), dim3(grid), dim3(kThreads), lds_elems * sizeof(T), s, a, tiles);
+  }
+  if (levels) {
+    // launched above
   } else if (a.aux0) {
-    return set_error(EKM_ERR_ARG, "EKM_HYBRID_FULL needs 16-B aligned full-field operands before it");
+    return set_error(EKM_ERR_ARG, "EKM_HYBRID_FULL needs full-field operands before it");
   } else if (!bc && aligned) {
     if (unroll >= 2)
       hipLaunchKernelGGL((map_fields<Op, T, 2>), dim3(grid), dim3(kThreads), 0, s, a, tiles);

@@ -113,9 +113,56 @@ struct OpWetBulbFromQ<EPT_IFS, T_NEWTON> {
     const T t = x[0], q = x[1], p = x[2];
     const T td = t_from_es(e_from_q(q, p));
     const T tl = lcl_t<LCL_DAVIES>(t, td);
-    const T te = t * m_exp2(T(k::K0_ifs * k::LOG2E) * q * m_rcp(tl));
+    const T xe = T(k::K0_ifs * k::LOG2E) * q * m_rcp(tl);  // log2 of exp(K0*q/t_lcl)
+    const T te = t * m_exp2(xe);
+    const T lte = m_log2(t * T(1.0 / 273.16)) + xe;        // log2(te/273.16) without waiting for te
     const T pp = m_exp2(T(k::kappa) * m_log2(p * T(1.0 / k::p0)));
-    y[0] = t_on_ma_newton_ifs_te(te, te, p, pp, T(0.1859e-5) * p + T(0.6512));
+    const TeFromTQP<T> exact{t, q, p};
+    y[0] = t_on_ma_newton_ifs_core(te, te, lte, p, pp, T(0.1859e-5) * p + T(0.6512), exact);
+  }
+};
+
+// ---- ops that keep a per-workgroup table in LDS -------------------------------------------------------
+// OpTable<Op>::elems > 0: the map kernels reserve `elems` values of LDS, call fill() once per workgroup
+// (all threads, followed by a barrier) and then OpTable<Op>::apply(x, y, rp, table) instead of Op::apply.
+// Op::apply itself stays the table-free statement of the same arithmetic (host twin, reference for tests).
+template <class Op>
+struct OpTable {
+  static constexpr int elems = 0;
+};
+
+// IFS bisection (the reference's DEFAULT t_method): es_mixed on the 4096-point search lattice
+struct BisectIfsTable {
+  static constexpr int elems = kBisectLattice;
+  template <class T>
+  EKM_HD static void fill(T* __restrict__ tab, int tid, int nthreads) {
+    for (int m = tid; m < kBisectLattice; m += nthreads) tab[m] = es_mixed(bisect_lattice_t<T>(m));
+  }
+};
+template <>
+struct OpTable<OpTOnMa<EPT_IFS, T_BISECT>> : BisectIfsTable {
+  template <class T>
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
+    y[0] = t_on_ma_bisect_ifs_tab(x[0], x[1], tab);
+  }
+};
+template <>
+struct OpTable<OpWetBulbFromTd<EPT_IFS, T_BISECT>> : BisectIfsTable {
+  template <class T>
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
+    y[0] = t_on_ma_bisect_ifs_tab(ept<EPT_IFS, false>(x[0], x[1], x[2]), x[2], tab);
+  }
+};
+template <>
+struct OpTable<OpWetBulbFromQ<EPT_IFS, T_BISECT>> : BisectIfsTable {
+  template <class T>
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
+    // theta_e (thermo.py:1169-1175) and the search share (p0/p)^kappa
+    const T t = x[0], q = x[1], p = x[2];
+    const T thf = m_exp2(T(-k::kappa) * m_log2(p * T(1.0 / k::p0)));
+    const T tl = lcl_t<LCL_DAVIES>(t, t_from_es(e_from_q(q, p)));
+    const T the = t * thf * m_exp2(T(k::K0_ifs * k::LOG2E) * q * m_rcp(tl));
+    y[0] = t_on_ma_bisect_ifs_tab(the, p, thf, tab);
   }
 };
 
@@ -127,6 +174,20 @@ EKM_HD T wbpt_from_ept(T e) {
 }
 EKM_OP_T2(OpWbptFromTd, METHOD, TM, 3, 1, y[0] = wbpt_from_ept<METHOD, TM>(ept<METHOD, false>(x[0], x[1], x[2]));)
 EKM_OP_T2(OpWbptFromQ, METHOD, TM, 3, 1, y[0] = wbpt_from_ept<METHOD, TM>(ept<METHOD, true>(x[0], x[1], x[2]));)
+template <>
+struct OpTable<OpWbptFromTd<EPT_IFS, T_BISECT>> : BisectIfsTable {
+  template <class T>
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
+    y[0] = t_on_ma_bisect_ifs_tab(ept<EPT_IFS, false>(x[0], x[1], x[2]), T(k::p0), tab);
+  }
+};
+template <>
+struct OpTable<OpWbptFromQ<EPT_IFS, T_BISECT>> : BisectIfsTable {
+  template <class T>
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
+    y[0] = t_on_ma_bisect_ifs_tab(ept<EPT_IFS, true>(x[0], x[1], x[2]), T(k::p0), tab);
+  }
+};
 // thermo.py:1678-1707
 EKM_OP(OpGasConstant, 1, 1, y[0] = T(k::Rd) + T(k::Rv - k::Rd) * x[0];)
 
@@ -151,7 +212,9 @@ struct OpPipelineFull {
     const T e = e_from_q(q, p);                       // thermo.py:130-131
     const T td = t_from_es(e);                        // es_comp.py:128-130
     const T tl = lcl_t<LCL_DAVIES>(t, td);            // thermo.py:961
-    const T the = th * m_exp2(T(k::K0_ifs * k::LOG2E) * q * m_rcp(tl));  // thermo.py:1175
+    const T xe = T(k::K0_ifs * k::LOG2E) * q * m_rcp(tl);
+    const T ex = m_exp2(xe);
+    const T the = th * ex;                            // thermo.py:1175
     y[0] = th;
     y[1] = es;
     y[2] = T(100.0) * e * m_rcp(es);                  // thermo.py:556
@@ -160,7 +223,9 @@ struct OpPipelineFull {
 #ifdef EKM_P5_NOWB  // diagnostic build: how long do the nine streams take with the wet-bulb arithmetic removed?
     y[5] = the + P.pp;
 #else
-    y[5] = t_on_ma_newton_ifs(the, P);                // thermo.py:1081-1159
+    // thermo.py:1081-1159; te = theta_e*(p/p0)^kappa = t*exp(K0*q/t_lcl): the pressure powers cancel
+    const TeFromTQP<T> exact{t, q, p};
+    y[5] = t_on_ma_newton_ifs_core(the, t * ex, m_log2(t * T(1.0 / 273.16)) + xe, p, P.pp, P.dinv, exact);
 #endif
   }
 };

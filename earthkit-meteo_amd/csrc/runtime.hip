@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -82,6 +83,25 @@ int device_cus(int dev) {
 
 int tuning_tiles_per_block() { return g_tiles_per_block.load(std::memory_order_relaxed); }
 int tuning_unroll() { return g_unroll.load(std::memory_order_relaxed); }
+
+static int env_int(const char* name, int dflt, int lo, int hi) {
+  const char* v = getenv(name);
+  if (!v || !*v) return dflt;
+  const long x = strtol(v, nullptr, 10);
+  return x < lo ? lo : (x > hi ? hi : (int)x);
+}
+int tuning_lev_per_wg() {
+  static const int v = env_int("EKM_LEV_PER_WG", 1, 1, 1024);
+  return v;
+}
+int tuning_hybrid_band_bytes() {
+  static const int v = env_int("EKM_HYBRID_BAND_KB", 4096, 4, 1 << 20);
+  return v * 1024;
+}
+int tuning_table_tiles() {
+  static const int v = env_int("EKM_TABLE_TILES", 16, 1, 4096);
+  return v;
+}
 
 // ---- synthetic atmosphere on the device (SURVEY.md 8d distribution) ---------
 // Counter-based: every value is a pure function of (seed, global point index),

@@ -81,11 +81,18 @@ EKM_HD float m_log(float x) { return std::log(x); }
 EKM_HD float m_pow(float x, float y) { return std::pow(x, y); }
 #endif
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(EKM_F64_LIBM)
-// fp64 on gfx950: there is no fp64 transcendental unit and the device libm pays for correctly
-// rounded results (pow alone is ~200 instructions).  The bar here is 1e-6 relative, so: reciprocal =
-// v_rcp_f64 seed + two Newton steps (exact to rounding), exp2 = round-to-nearest split + degree-12
-// Taylor of e^(f ln2) + v_ldexp_f64 (<= 2e-16 relative), log2 = v_frexp + atanh series in
-// s = (m-1)/(m+1) to s^21 (<= 3e-16), pow = exp2(y*log2(x)).  inf / 0 / NaN behave as in libm.
+// fp64 on gfx950: there is no fp64 transcendental unit and the device libm pays for correctly rounded
+// results (pow alone is ~200 instructions).  Measured issue cost (tools/microbench/valu_rates_f64.hip):
+// v_fma_f64 5.2 clk per wave, v_rcp_f64 17 clk.  The parity bar for fp64 is 1e-6 relative, so by default
+// the three primitives are built to ~1e-11 (five orders inside the bar, one order inside the 1e-8 the
+// GPU tests assert against the reference's fp64 goldens):
+//   rcp  = v_rcp_f64 seed + ONE Newton step (<= 1e-14);
+//   exp2 = round-to-nearest split + degree-8 near-minimax polynomial of e^(f ln2) + v_ldexp_f64 (1.1e-12);
+//   log2 = v_frexp + 2*atanh(s), s = (m-1)/(m+1), as s*q(s^2) with a degree-4 near-minimax q (4.2e-12);
+//   pow  = exp2(y*log2(x)).
+// -DEKM_F64_EXACT selects the <= 3e-16 versions (two Newton steps, degree-12 Taylor, atanh series to s^21)
+// for A/B comparison.  inf / 0 / NaN behave as in libm in both.
+#if defined(EKM_F64_EXACT)
 EKM_HD double m_rcp(double x) {
   const double r0 = __builtin_amdgcn_rcp(x);
   double e = __builtin_fma(-x, r0, 1.0);
@@ -141,6 +148,59 @@ EKM_HD double m_log2(double x) {
   if (x < 0.0 || x != x) r = __builtin_nan("");
   return r;
 }
+#else
+// (Wave-uniform skipping of the special-operand fix-ups was tried and is slower: 19.9 vs 17.8 ms for the full
+// pipeline -- the branches stop the compiler from interleaving the four points of a lane.)
+EKM_HD double m_rcp(double x) {
+  const double r0 = __builtin_amdgcn_rcp(x);
+  const double e = __builtin_fma(-x, r0, 1.0);
+  const double r = __builtin_fma(r0, e, r0);
+  return __builtin_isfinite(r) ? r : r0;  // x = 0, inf, NaN: keep the hardware answer (inf, 0, NaN)
+}
+EKM_HD double m_div(double a, double b) { return a * m_rcp(b); }
+EKM_HD double m_exp2(double x) {
+  const double xc = __builtin_fmin(__builtin_fmax(x, -1100.0), 1100.0);
+  const double n = __builtin_rint(xc);
+  const double y = (xc - n) * 0.69314718055994530942;  // |y| <= 0.3466
+  double p = 2.4876145736304345e-05;                     // degree-8 interpolant of e^y at Chebyshev nodes
+  p = __builtin_fma(p, y, 0.00019915866953885213);
+  p = __builtin_fma(p, y, 0.0013888821718752312);
+  p = __builtin_fma(p, y, 0.008333266097830411);
+  p = __builtin_fma(p, y, 0.041666666890669196);
+  p = __builtin_fma(p, y, 0.16666666891046666);
+  p = __builtin_fma(p, y, 0.49999999999798606);
+  p = __builtin_fma(p, y, 0.9999999999797852);
+  p = __builtin_fma(p, y, 1.0);
+  const double r = __builtin_amdgcn_ldexp(p, (int)n);
+  return x != x ? x : r;
+}
+EKM_HD double m_log2(double x) {
+#if defined(EKM_F64_LOG_SPLIT_SELECT)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  if (m < 0.70710678118654752440) {
+    m *= 2.0;
+    e -= 1;
+  }
+#else
+  // x = m * 2^e with m in [0.7071, 1.4142): the exponent of x*sqrt(2) puts the split at sqrt(1/2)
+  const int e = __builtin_amdgcn_frexp_exp(x * 1.41421356237309504880) - 1;
+  const double m = __builtin_amdgcn_ldexp(x, -e);
+#endif
+  const double s = (m - 1.0) * m_rcp(m + 1.0);  // |s| <= 0.1716
+  const double z = s * s;
+  double p = 0.1180818033212343;                   // atanh(s)/s on z = s^2 in [0, 0.0295], degree 4
+  p = __builtin_fma(p, z, 0.14267525468490147);
+  p = __builtin_fma(p, z, 0.20000192337193154);
+  p = __builtin_fma(p, z, 0.3333333262373743);
+  p = __builtin_fma(p, z, 1.0000000000041798);
+  double r = __builtin_fma(p * s, 2.0 * 1.44269504088896340736, (double)e);
+  if (x == 0.0) r = -__builtin_inf();
+  if (x == __builtin_inf()) r = x;
+  if (x < 0.0 || x != x) r = __builtin_nan("");
+  return r;
+}
+#endif
 EKM_HD double m_exp(double x) { return m_exp2(x * 1.44269504088896340736); }
 EKM_HD double m_log(double x) { return m_log2(x) * 0.69314718055994530942; }
 EKM_HD double m_pow(double x, double y) { return m_exp2(y * m_log2(x)); }
@@ -442,6 +502,11 @@ EKM_HD float wbpt_direct(float e) {
   return e - m_exp(m_div(a, b));
 }
 
+// sign(r)*dt of the reference's `t += sign(r)*dt` without branches: +-dt by sign-bit transfer, r itself
+// (0 -> no move, NaN -> NaN) when r is zero or unordered
+EKM_HD float bisect_step(float r, float dt) { return (r < 0.0f || r > 0.0f) ? __builtin_copysignf(dt, r) : r; }
+EKM_HD double bisect_step(double r, double dt) { return (r < 0.0 || r > 0.0) ? __builtin_copysign(dt, r) : r; }
+
 // Moist-adiabat inversion by 12 fixed halvings (thermo.py:1055-1079)
 // IFS variant of the 12 halvings with the loop-invariant (p0/p)^kappa hoisted and the two
 // divisions of G_sat = -K0*qs/t merged into one reciprocal (same residual, thermo.py:1075,1177-1182).
@@ -457,9 +522,51 @@ EKM_HD T t_on_ma_bisect_ifs(T e, T p) {
     if ((p - es) < T(k::eps_default)) v = nan_v<T>();
     const T g = T(-k::K0_ifs * k::eps * k::LOG2E) * es * m_rcp(v * t);  // log2 of exp(-K0*qs/t)
     dt *= T(0.5);
-    t += m_sign(e * m_exp2(g) - t * thf) * dt;
+    t += bisect_step(e * m_exp2(g) - t * thf, dt);
   }
   return t;
+}
+
+// The same 12 halvings with es_mixed read from a table.  The search only ever evaluates the saturated
+// parcel at the lattice temperatures t_m = 253.16 + (m - 2048)*120/2048, m in [1, 4095]: float32(253.16)
+// is a multiple of 2^-15 and every step is a multiple of 15/512, so the reference's accumulated fp32 `t`
+// IS the lattice value, bit for bit (checked exhaustively in tests/test_engine_host.py), and es_mixed(t_m)
+// can be tabulated once per workgroup in LDS (4096 x 4 B = 16 KiB of the 160 KiB).  Per step that replaces
+// 1-2 rcp + 1-2 exp2 + the blend by one ds_read; the residual and its sign are computed exactly as in
+// t_on_ma_bisect_ifs, so the result is bit-identical to it.
+constexpr int kBisectLattice = 4096;
+
+template <class T>
+EKM_HD T bisect_lattice_t(int m) {
+  return T(k::T0 - 20) + T(m - kBisectLattice / 2) * T(120.0 / 2048);
+}
+
+// `thf` = (p0/p)^kappa, `e` = theta_e.  The lattice index is recovered from t itself (t is exactly on the
+// lattice, so (t - 253.16)*2048/120 + 2048 is an integer up to rounding far below 1/2; NaN converts to 0,
+// a valid entry -- the result is NaN from then on anyway).
+template <class T>
+EKM_HD T t_on_ma_bisect_ifs_tab(T e, T p, T thf, const T* __restrict__ es_tab) {
+  T t = T(k::T0 - 20);
+  T dt = T(120.0);
+#ifndef EKM_BISECT_UNROLL
+#define EKM_BISECT_UNROLL 12
+#endif
+#pragma unroll EKM_BISECT_UNROLL
+  for (int it = 0; it < 12; ++it) {
+    const int m = (int)(t * T(2048.0 / 120.0) + T(kBisectLattice / 2 + 0.5 - (k::T0 - 20) * (2048.0 / 120.0)));
+    const T es = es_tab[m];
+    T v = p + T(k::eps - 1) * es;
+    if ((p - es) < T(k::eps_default)) v = nan_v<T>();
+    const T g = T(-k::K0_ifs * k::eps * k::LOG2E) * es * m_rcp(v * t);  // log2 of exp(-K0*qs/t)
+    dt *= T(0.5);
+    t += bisect_step(e * m_exp2(g) - t * thf, dt);
+  }
+  return t;
+}
+
+template <class T>
+EKM_HD T t_on_ma_bisect_ifs_tab(T e, T p, const T* __restrict__ es_tab) {
+  return t_on_ma_bisect_ifs_tab(e, p, m_exp2(T(-k::kappa) * m_log2(p * T(1.0 / k::p0))), es_tab);
 }
 
 template <int METHOD, class T>
@@ -475,6 +582,63 @@ EKM_HD T t_on_ma_bisect(T e, T p) {
     t += m_sign(e * m_exp(g) - th) * dt;
   }
   return t;
+}
+
+// ---- Davies-Jones regime selection (thermo.py:1114-1128) -------------------------------------------
+// The initial guess switches formula where c_te crosses D(p), 1 and 0.4, and the guesses on the two sides
+// of a threshold differ (by ~2 K at 10 hPa), so a point whose c_te is within rounding noise of a threshold
+// must take the reference's decision, not the one our differently rounded fp32 c_te happens to give.  The
+// fp32 kernels therefore re-derive the four predicates in DOUBLE on the rare lanes whose fast c_te lies
+// within kTieBand of a threshold (a wave-uniform branch: ~0.1 % of the waves of the benchmark field enter
+// it): te is recomputed from the op's own inputs by `te_exact()`, then c_te and D in the reference's operator
+// order with the reference's fp32-rounded constants -- power(t0/te, lambda), 1/(0.1859e-5*p + 0.6512),
+// c_te > D, 1 <= c_te <= D, 0.4 <= c_te < 1, c_te < 0.4 -- i.e. what the reference's fp32 sequence computes
+// up to its own rounding noise.  The guess FORMULAS stay in fp32 (they are continuous in c_te).
+struct Regime {
+  bool r1, r2, r3, r4;  // c_te > D | 1 <= c_te <= D | 0.4 <= c_te < 1 | c_te < 0.4  (all false for NaN)
+};
+
+constexpr double kTieBand = 4e-6;  // > 3x the worst fp32 error of the fast c_te (te ~3e-7, x lambda, + exp2/log2)
+
+struct TeNone {  // no exact te available (fp64 kernels never need one)
+  static constexpr bool have = false;
+  EKM_HD double operator()() const { return 0.0; }
+};
+
+// te = ept*(p/p0)^kappa (thermo.py:1109-1110) from a given theta_e
+template <class T>
+struct TeFromEpt {
+  static constexpr bool have = true;
+  T e, p;
+  EKM_HD double operator()() const {
+    return double(e) * m_exp2(double(float(k::kappa)) * m_log2(double(p) * (1.0 / k::p0)));  // p0 = 1e5 is exact in fp32
+  }
+};
+
+template <class T, class TeExact>
+EKM_HD Regime davies_regime(T c_te, T cd, T p, const TeExact& te_exact) {
+  Regime r;
+  r.r1 = cd > T(1);
+  r.r2 = T(1) <= c_te && cd <= T(1);
+  r.r3 = T(0.4) <= c_te && c_te < T(1);
+  r.r4 = c_te < T(0.4);
+  if constexpr (TeExact::have && sizeof(T) == 4) {
+    const T tau = T(kTieBand);
+    const T d1 = cd - T(1), d2 = c_te - T(1), d3 = c_te - T(0.4);
+    const bool tie = (d1 < tau && d1 > -tau) || (d2 < tau && d2 > -tau) || (d3 < T(0.4) * tau && d3 > T(-0.4) * tau);
+    if (EKM_ANY(tie)) {
+      const double te = te_exact();
+      const double c = m_exp2(double(float(k::lambda)) * m_log2(double(273.16f) * m_rcp(te)));
+      const double D = m_rcp(double(0.1859e-5f) * double(p) + double(0.6512f));
+      if (tie) {
+        r.r1 = c > D;
+        r.r2 = 1.0 <= c && c <= D;
+        r.r3 = double(0.4f) <= c && c < 1.0;
+        r.r4 = c < double(0.4f);
+      }
+    }
+  }
+  return r;
 }
 
 // Pressure-only terms of the moist-adiabat inversion.  With p a level vector they are
@@ -500,29 +664,20 @@ EKM_HD PTerms<T> pterms(T p) {
 
 // Davies-Jones inversion for the IFS theta_e (the path BASELINE.json configs 4/5 name):
 // same regimes, same single Newton step as thermo.py:1081-1159 + 1184-1197, with the
-// transcendental count cut to the minimum: powers as exp2 of one shared log2, c_te > D
-// tested as c_te*(1/D) > 1, 1/c_te as exp2 of the negated exponent, reciprocals shared
-// between qs and its slope, and regime / phase work skipped by whole waves that do not
-// need it.
-template <class T>
-EKM_HD T t_on_ma_newton_ifs_te(T e, T te, T p, T pp, T dinv);
-
-template <class T>
-EKM_HD T t_on_ma_newton_ifs(T e, const PTerms<T>& P) {
-  return t_on_ma_newton_ifs_te(e, e * P.pp, P.p, P.pp, P.dinv);  // te = ept*(p/p0)^kappa, thermo.py:1110
-}
-
-// `e` is only the value the guess keeps when c_te is NaN (the result is NaN then anyway).
-template <class T>
-EKM_HD T t_on_ma_newton_ifs_te(T e, T te, T p, T pp, T dinv) {
+// transcendental count cut to the minimum: powers as exp2 of one shared log2, 1/c_te as exp2 of
+// the negated exponent, the Newton residual 1 - c_te/f from ONE exp2 (the exponents of c_te, c_tw and
+// exp(G) add), reciprocals shared between qs and its slope, and regime / phase work skipped by whole
+// waves that do not need it.  `lte` = log2(te/273.16); `te` itself is only needed by the regime-1 guess.
+template <class T, class TeExact>
+EKM_HD T t_on_ma_newton_ifs_core(T e, T te, T lte, T p, T pp, T dinv, const TeExact& te_exact) {
   const T lam = T(k::lambda);
-  const T lte = m_log2(te * T(1.0 / 273.16));
   const T c_te = m_exp2(-lam * lte);  // (t0/te)^lambda
   const T cd = c_te * dinv;           // c_te / D
+  const Regime R = davies_regime(c_te, cd, p, te_exact);
 
   // initial guess in deg C; later regimes overwrite earlier ones (thermo.py:1114-1128)
   T tw = e;
-  if (EKM_ANY(cd > T(1))) {
+  if (EKM_ANY(R.r1)) {
     T es, des;
     es_slope_mixed(te, es, des);
     T v = p - es;
@@ -532,36 +687,66 @@ EKM_HD T t_on_ma_newton_ifs_te(T e, T te, T p, T pp, T dinv) {
     T bw = T(2675 * k::eps) * des * rv;        // A*ws*des/es
     if (!(es > T(0))) bw = nan_v<T>();         // the reference's 0*0/0 where es underflows
     const T g1 = (te - T(273.16)) - aw * m_rcp(T(1) + bw);
-    if (cd > T(1)) tw = g1;
+    if (R.r1) tw = g1;
   }
   const T k1 = poly2(pp, -53.737, 137.81, -38.5);
   const T k2 = poly2(pp, -0.384, 56.831, -4.392);
   const T k2m = k2 - T(1.21);
-  if (T(1) <= c_te && cd <= T(1)) tw = k1 - k2 * c_te;
-  if (T(0.4) <= c_te && c_te < T(1)) tw = (k1 - T(1.21)) - k2m * c_te;
-  if (EKM_ANY(c_te < T(0.4))) {
+  if (R.r2) tw = k1 - k2 * c_te;
+  if (R.r3) tw = (k1 - T(1.21)) - k2m * c_te;
+  if (EKM_ANY(R.r4)) {
     const T g4 = (k1 - T(2.66)) - k2m * c_te + T(0.58) * m_exp2(lam * lte);  // 0.58/c_te
-    if (c_te < T(0.4)) tw = g4;
+    if (R.r4) tw = g4;
   }
   tw = tw + T(k::T0);
 
-  // one Newton step (thermo.py:1132-1149, 1184-1197)
+  // one Newton step (thermo.py:1132-1149, 1184-1197): tw -= (f - c_te)/(f*dlnf) = (1 - c_te/f)/dlnf with
+  // c_te/f = exp2(lambda*(log2(tw/t0) - log2(te/t0)) + lambda*K0*log2(e)*qs/tw)
   const T rtw = m_rcp(tw);
-  const T c_tw = m_exp2(-lam * m_log2(tw * T(1.0 / 273.16)));
+  const T ltw = m_log2(tw * T(1.0 / 273.16));
   T es, des;
   es_slope_mixed(tw, es, des);
   T v = p + T(k::eps - 1) * es;
   if ((p - es) < T(k::eps_default)) v = nan_v<T>();
   const T rv = m_rcp(v);
   const T qs = T(k::eps) * es * rv;
-  const T f = c_tw * m_exp2(T(-k::lambda * k::K0_ifs * k::LOG2E) * qs * rtw);
+  const T qr = qs * rtw;
+  const T ratio = m_exp2(lam * (ltw - lte) + T(k::lambda * k::K0_ifs * k::LOG2E) * qr);
   const T dqs = T(k::eps) * des * p * (rv * rv);
-  const T dg = T(k::K0_ifs) * rtw * (dqs - qs * rtw);
+  const T dg = T(k::K0_ifs) * rtw * (dqs - qr);
   const T dlnf = -lam * (rtw + dg);
-  tw -= (f - c_te) * m_rcp(f * dlnf);
+  // f == 0 (tw -> inf) or f == inf make the reference's (f - c_te)/(f*dlnf) NaN; so does ratio = inf/NaN here
+  tw -= (T(1) - ratio) * m_rcp(dlnf);
   if (tw <= T(0)) tw = nan_v<T>();  // thermo.py:1155
   return tw;
 }
+
+// theta_e given (temperature_on_moist_adiabat, wet-bulb from dewpoint, theta_w by Newton)
+template <class T>
+EKM_HD T t_on_ma_newton_ifs(T e, const PTerms<T>& P) {
+  const T te = e * P.pp;  // thermo.py:1110
+  const TeFromEpt<T> exact{e, P.p};
+  return t_on_ma_newton_ifs_core(e, te, m_log2(te * T(1.0 / 273.16)), P.p, P.pp, P.dinv, exact);
+}
+
+// te = theta_e*(p/p0)^kappa for the IFS theta_e from specific humidity (thermo.py:1169-1175 with td from
+// q, thermo.py:702-735): the two pressure powers cancel, te = t*exp(K0*q/t_lcl).  The fp32 kernels use the
+// fast chain below (`x` = log2 of the exponential factor); this functor is the same quantity in double with
+// the reference's fp32-rounded constants, for the regime tie-break only.
+template <class T>
+struct TeFromTQP {
+  static constexpr bool have = true;
+  T t, q, p;
+  EKM_HD double operator()() const {
+    const double td_ = double(t), qd = double(q), pd = double(p);
+    const double e = pd * qd * m_rcp(double(float(k::eps)) + double(float(k::q_c)) * qd);
+    const double v = m_log2(e * m_rcp(double(float(k::C1)))) * k::LN2;
+    const double td = (v * double(float(k::C4W)) - double(float(k::C3W * k::T0))) * m_rcp(v - double(float(k::C3W)));
+    const double tl = td - (double(0.212f) + double(1.571e-3f) * (td - double(float(k::T0))) -
+                            double(4.36e-4f) * (td_ - double(float(k::T0)))) * (td_ - td);
+    return td_ * m_exp2(double(float(k::K0_ifs)) * k::LOG2E * qd * m_rcp(tl));
+  }
+};
 
 // Davies-Jones (2008): regime initial guess + exactly one Newton step
 // (max_iter = 1, thermo.py:1104), tw <= 0 -> NaN (thermo.py:1081-1159).
@@ -574,7 +759,6 @@ EKM_HD T t_on_ma_newton(T e, T p) {
   const T pp = m_pow(pr, T(k::kappa));
   const T te = e * pp;
   const T c_te = m_pow(m_div(t0, te), lam);
-  const T D = m_rcp(T(0.1859e-5) * p + T(0.6512));
 
   // initial guess (deg C); later regimes overwrite earlier ones (thermo.py:1114-1128)
   T tw = e;
@@ -586,10 +770,12 @@ EKM_HD T t_on_ma_newton(T e, T p) {
     const T g1 = te - t0 - m_div(aw, T(1) + m_div(aw * des, es));
     const T k1 = poly2(pp, -53.737, 137.81, -38.5);
     const T k2 = poly2(pp, -0.384, 56.831, -4.392);
-    if (c_te > D) tw = g1;
-    if (T(1) <= c_te && c_te <= D) tw = k1 - k2 * c_te;
-    if (T(0.4) <= c_te && c_te < T(1)) tw = (k1 - T(1.21)) - (k2 - T(1.21)) * c_te;
-    if (c_te < T(0.4)) tw = (k1 - T(2.66)) - (k2 - T(1.21)) * c_te + m_div(T(0.58), c_te);
+    const TeFromEpt<T> exact{e, p};
+    const Regime R = davies_regime(c_te, c_te * (T(0.1859e-5) * p + T(0.6512)), p, exact);
+    if (R.r1) tw = g1;
+    if (R.r2) tw = k1 - k2 * c_te;
+    if (R.r3) tw = (k1 - T(1.21)) - (k2 - T(1.21)) * c_te;
+    if (R.r4) tw = (k1 - T(2.66)) - (k2 - T(1.21)) * c_te + m_div(T(0.58), c_te);
   }
   tw = tw + T(k::T0);
 

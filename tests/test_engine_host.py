@@ -110,3 +110,24 @@ def test_leading_axis_bounds(n0, k):
     assert all(hi == lo2 for (_, hi), (lo2, _) in zip(b, b[1:]))
     sizes = [hi - lo for lo, hi in b]
     assert max(sizes) - min(sizes) <= 1
+
+
+def test_bisection_lattice_is_exact_in_fp32():
+    """The LDS table of the IFS bisection (csrc/thermo_math.hpp::t_on_ma_bisect_ifs_tab) relies on this: the
+    reference's accumulated fp32 temperature (thermo.py:1055-1079: t = 253.16; dt /= 2; t += sign*dt) equals
+    253.16f + M*120/2048 bit for bit at each of the 12 evaluations, for EVERY one of the 2^11 sign paths."""
+    t0 = np.float32(273.16 - 20)
+    step = np.float32(120.0 / 2048)
+    paths = np.arange(2 ** 11, dtype=np.int64)
+    t = np.full(paths.size, t0, np.float32)
+    m = np.zeros(paths.size, np.int64)
+    dt = np.float32(120.0)
+    for it in range(12):
+        lattice = (m.astype(np.float32) * step + t0).astype(np.float32)  # what the kernel's table is filled with
+        assert lattice.dtype == np.float32 and np.array_equal(lattice, t), it
+        assert np.array_equal(lattice.astype(np.float64), np.float64(t0) + m * (120.0 / 2048))  # exactly representable
+        dt = np.float32(dt / np.float32(2))
+        s = np.where((paths >> min(it, 10)) & 1, 1, -1)
+        t = (t + s.astype(np.float32) * dt).astype(np.float32)
+        m = m + s * (2048 >> (it + 1))
+    assert -2048 < m.min() and m.max() < 2048

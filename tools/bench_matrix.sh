@@ -1,0 +1,24 @@
+#!/bin/bash
+# One bench.py line per (workload, pressure mode): the roofline table of DESIGN.md section 4.
+#   tools/bench_matrix.sh <out.jsonl> [extra bench.py args...]
+OUT=${1:?out.jsonl}; shift
+: > "$OUT"
+for wl in full p3 wetbulb wetbulb_bisect theta rh ept; do
+  for pm in field level hybrid; do
+    timeout -k 10 120 python3 bench.py --workload $wl --pmode $pm --steps 20 --warmup 5 --no-cpu-baseline "$@" >> "$OUT" 2>> "$OUT.err" || echo "{\"failed\": \"$wl $pm\"}" >> "$OUT"
+  done
+done
+timeout -k 10 120 python3 bench.py --workload svp --steps 20 --warmup 5 --no-cpu-baseline "$@" >> "$OUT" 2>> "$OUT.err"
+timeout -k 10 120 python3 bench.py --workload hybrid_levels --steps 20 --warmup 5 "$@" >> "$OUT" 2>> "$OUT.err"
+timeout -k 10 120 python3 bench.py --workload geopotential --steps 20 --warmup 5 "$@" >> "$OUT" 2>> "$OUT.err"
+python3 - "$OUT" <<'PY'
+import json, sys
+for ln in open(sys.argv[1]):
+    d = json.loads(ln)
+    if "failed" in d:
+        print("FAILED", d["failed"]); continue
+    r, c = d["roofline"], d["config"]
+    print(f"{r['kernel'][:44]:44s} {c['p_mode']:6s} {d['dtype']} {r['bytes_per_point']:3d} B/pt  {r['kernel_ms']:7.3f} ms  "
+          f"{r['achieved']:7.1f} GB/s  frac {r['frac']:.3f}  parity {d['parity']['ok'] if d['parity'] else None} "
+          f"maxrel {d['parity']['max_rel_err'] if d['parity'] else None}")
+PY
