@@ -490,14 +490,8 @@ def check_parity(args, t, q, p, plev, outs, sh, nlev, np_dtype, hyb=None):
         pl = plev.to_host()
         hp = np.concatenate([np.full(256, pl[lev], np_dtype) for lev, _ in wins])
     want = (hp,) if args.workload == "hybrid_levels" else oracle_call(args.workload, ht, hq, hp)
-    # points whose Davies-Jones regime is decided by rounding in the reference itself are excluded
-    # from the wet-bulb comparison and counted (oracle/conditioning.py)
+    # No point is excluded: the kernels settle Davies-Jones regime ties in double (csrc/thermo_math.hpp::davies_regime)
     edge = None
-    if args.workload in ("full", "wetbulb"):
-        from oracle import conditioning
-
-        edge = conditioning.newton_regime_boundary("pipeline_full", [ht, hq, hp], {},
-                                                   1e-5 if args.dtype == "f32" else 1e-13)
     bis = args.workload == "wetbulb_bisect"
     noisy = None
     if bis:  # points where sign() of the reference's own residual is rounding noise are excluded and counted

@@ -73,27 +73,67 @@ def newton_regime_boundary(func, inputs, kwargs, thresh):
     return conditioning.newton_regime_boundary(func, inputs, kwargs, thresh)
 
 
+# ---- budget ledger: every relaxation a test uses is recorded and printed at the end of the run --------
+LEDGER = []  # (what, kind, used, allowed, n)
+
+# Measured on MI355X (round 2, profiles/r02_parity_budgets.txt), limits set to ~2x the largest use seen:
+BISECT_UNSTABLE_FRACTION = 0.08   # reference-unstable bisect points; largest seen 5.4 % (the reference's 480-row table: 1/6 of its rows are exactly saturated)
+BOUNDARY_VIOLATION_FRACTION = 0.02  # of the regime-boundary points, how many may miss the bar (the fp32 reference's own flips); measured: 0 of 28,807 on the benchmark field
+ILL_CONDITIONED_FRACTION = 1e-4   # Bolton Newton points needing max(rtol, 4*delta)
+
+
+def _record(what, kind, used, allowed, n):
+    LEDGER.append((what, kind, int(used), float(allowed), int(n)))
+
+
 def assert_parity(got, want, tag, what, bisect=False, rtol=None, unstable=None, ref64=None, max_relaxed=None):
-    """`ref64` (fp32 comparisons only): the reference's fp64 result on the same fp32 inputs.  Where
-    the reference's own fp32 output sits delta away from it (an ill-conditioned point of the
-    reference's algorithm, e.g. the Bolton-35 Newton step near p = p0), a differently rounded fp32
-    evaluation cannot be expected closer than a few delta: the bar there is max(rtol, 4*delta), and
-    at most 1e-4 of the points may need it."""
+    """`unstable`: points where the REFERENCE's own algorithm takes a rounding-determined decision, always
+    identified from the reference (the oracle in fp64), never from the output under test.
+      * bisect: excluded and counted (<= BISECT_UNSTABLE_FRACTION of the points, at least 3);
+      * Newton (Davies-Jones regime boundaries): still COMPARED -- the kernels settle near-threshold lanes in
+        double in the reference's operator order -- but up to BOUNDARY_VIOLATION_FRACTION of them (at least 1)
+        may miss the bar (none when there are fewer than 50), which is what the fp32 reference's own rounding flips
+        could amount to; measured use: 0 (profiles/r02_parity_budgets.txt).
+    `ref64` (fp32 comparisons only): the reference's fp64 result on the same fp32 inputs.  Where the
+    reference's own fp32 output sits delta away from it (an ill-conditioned point of the reference's
+    algorithm, e.g. the Bolton-35 Newton step near p = p0), the bar there is max(rtol, 4*delta), and at
+    most ILL_CONDITIONED_FRACTION of the points (at least 3) may need it."""
     rtol = RTOL[tag] if rtol is None else rtol
-    if unstable is not None and unstable.any():
-        lim = max(3, 0.10 * unstable.size) if bisect else max(3, 2e-4 * unstable.size)
-        assert unstable.sum() <= lim, f"{what}: {unstable.sum()} reference-unstable points"
-        keep = ~np.asarray(unstable).ravel()
-        got = np.asarray(got).ravel()[keep]
-        want = np.asarray(want).ravel()[keep]
-        if ref64 is not None:
-            ref64 = np.asarray(ref64).ravel()[keep]
+    boundary = None
+    if unstable is not None and np.any(unstable):
+        unstable = np.asarray(unstable).ravel()
+        if bisect:
+            # the reference's 480-row table has 1/6 of its rows exactly saturated (5.4 % unstable); seeded synthetic data 2 %
+            lim = max(3, (BISECT_UNSTABLE_FRACTION if unstable.size <= 1000 else 0.5 * BISECT_UNSTABLE_FRACTION) * unstable.size)
+            _record(what, "bisect: reference-unstable points excluded", unstable.sum(), lim, unstable.size)
+            assert unstable.sum() <= lim, f"{what}: {unstable.sum()} reference-unstable points (limit {lim:.0f})"
+            keep = ~unstable
+            got = np.asarray(got).ravel()[keep]
+            want = np.asarray(want).ravel()[keep]
+            if ref64 is not None:
+                ref64 = np.asarray(ref64).ravel()[keep]
+        else:
+            lim = max(3, 2e-4 * unstable.size)
+            assert unstable.sum() <= lim, f"{what}: {unstable.sum()} regime-boundary points (limit {lim:.0f})"
+            boundary = unstable
     assert_same_nonfinite(got, want, what)
-    r = rel_err(got, want)
+    r = rel_err(got, want).ravel()
+    if boundary is not None:  # compared, with a small allowance for the reference's own flips
+        over = int((r[boundary] > rtol).sum())
+        allowed = int(BOUNDARY_VIOLATION_FRACTION * boundary.sum())  # none for fewer than 50 boundary points
+        _record(what, "newton: regime-boundary points beyond the bar", over, allowed, int(boundary.sum()))
+        assert over <= allowed, (f"{what}: {over} of {int(boundary.sum())} regime-boundary points beyond {rtol:g} "
+                                 f"(allowed {allowed}); worst {r[boundary].max():.3e}")
+        r = r[~boundary]
+        if ref64 is not None:
+            ref64 = np.asarray(ref64).ravel()[~boundary]
+            want = np.asarray(want).ravel()[~boundary]
     if not bisect and ref64 is not None:
-        bar = np.maximum(rtol, 4.0 * rel_err(want, ref64))
+        bar = np.maximum(rtol, 4.0 * rel_err(want, ref64).ravel())
         relaxed = int((bar > rtol).sum())
-        allowed = max(3, 1e-4 * r.size) if max_relaxed is None else max_relaxed
+        allowed = max(3, ILL_CONDITIONED_FRACTION * r.size) if max_relaxed is None else max_relaxed
+        if relaxed:
+            _record(what, "newton: ill-conditioned points at max(rtol, 4*delta)", relaxed, allowed, r.size)
         assert relaxed <= allowed, f"{what}: {relaxed} ill-conditioned points in the reference"
         bad = r > bar
         assert not bad.any(), f"{what}: rel err {r[bad].max():.3e} beyond max({rtol:g}, 4*delta) at {np.flatnonzero(bad)[:4]}"
@@ -108,5 +148,6 @@ def assert_parity(got, want, tag, what, bisect=False, rtol=None, unstable=None, 
     d = np.abs(got - want)[fin]
     assert d.size == 0 or d.max() <= 2 * BISECT_QUANTUM * (1 + 1e-6), f"{what}: bisect off by {d.max():.4f} K (> 2 quanta)"
     flips = int((r > rtol).sum())
+    _record(what, "bisect: points one or two quanta off", flips, max(1, BISECT_FLIP_FRACTION * r.size), r.size)
     assert flips <= max(1, BISECT_FLIP_FRACTION * r.size), f"{what}: {flips}/{r.size} bisect sign flips"
     return float(r.max()) if r.size else 0.0

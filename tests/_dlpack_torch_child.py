@@ -1,0 +1,68 @@
+"""Child process of tests/test_gpu_streaming.py::test_dlpack_with_torch_as_foreign_producer_and_consumer.
+
+torch (a FOREIGN ROCm array library; test infrastructure only, the product never imports it) is imported and
+initialised first, then ekm_hip.  Exit code 77 = torch has no ROCm device here (skip)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "earthkit-meteo_amd")]
+
+import numpy as np  # noqa: E402
+
+try:
+    import torch
+except ImportError:
+    print("torch is not installed")
+    sys.exit(77)
+if not torch.cuda.is_available():
+    print("torch sees no ROCm device")
+    sys.exit(77)
+torch.zeros(1, device="cuda").cpu()  # initialise torch's HIP context before the other library loads
+
+import ekm_hip as ek  # noqa: E402
+from oracle import synthetic  # noqa: E402
+
+np.seterr(all="ignore")
+t, q, p, _ = synthetic.make_fields(4, 1 << 20, dtype=np.float32, seed=5)
+d = [ek.to_device(a) for a in (t, q, p)]
+want = ek.thermo.relative_humidity_from_specific_humidity(*d).to_host()  # our own path, our own memory
+
+dev = torch.device("cuda", ek.current_device())
+side = torch.cuda.Stream(device=dev)
+with torch.cuda.stream(side):  # producer work on a non-default torch stream, still in flight at hand-over
+    tt = torch.from_numpy(t).to(dev) * 1.0
+    tq = torch.from_numpy(q).to(dev) * 1.0
+    tp = torch.from_numpy(p).to(dev) * 1.0
+    dt_, dq_, dp_ = (ek.from_dlpack(x) for x in (tt, tq, tp))  # hands torch OUR stream: torch orders its work before it
+assert dt_.ptr == tt.data_ptr() and dq_.ptr == tq.data_ptr() and dp_.ptr == tp.data_ptr(), "copy on the way in"
+assert dt_.shape == t.shape and dt_.dtype == np.float32 and dt_.device == ek.current_device()
+rh = ek.thermo.relative_humidity_from_specific_humidity(dt_, dq_, dp_)
+back = torch.from_dlpack(rh)  # torch passes ITS current stream: ordered after our kernel on the device
+assert back.data_ptr() == rh.ptr and tuple(back.shape) == t.shape and back.dtype == torch.float32, "copy on the way out"
+doubled = (back * 2.0).cpu().numpy()
+assert np.array_equal(back.cpu().numpy(), want, equal_nan=True), "kernel on torch memory differs from our own path"
+assert np.array_equal(doubled, want * 2.0, equal_nan=True)
+
+# a second round on our own non-default stream: producer is handed that stream
+s1 = ek.stream_create()
+ek.set_stream(s1)
+big = torch.rand(1 << 24, device=dev) * 50.0 + 250.0   # asynchronous on torch's stream
+es = ek.thermo.saturation_vapour_pressure(ek.from_dlpack(big))
+got = torch.from_dlpack(es).cpu().numpy()
+ek.set_stream(None)
+ref = ek.thermo.saturation_vapour_pressure(ek.to_device(big.cpu().numpy())).to_host()
+assert np.array_equal(got, ref), "stream hand-over lost ordering"
+
+# rejections
+for bad, exc in ((torch.ones(4), TypeError), (torch.ones(4, dtype=torch.int32, device=dev), TypeError),
+                 (torch.ones(4, 4, device=dev).t(), ValueError)):
+    try:
+        ek.from_dlpack(bad)
+    except exc:
+        pass
+    else:
+        raise AssertionError(f"from_dlpack accepted {bad.dtype} {bad.device} contiguous={bad.is_contiguous()}")
+del back, rh, dt_, dq_, dp_, es
+ek.synchronize()
+print("DLPACK_TORCH_OK: zero-copy in and out, stream-ordered, torch", torch.__version__)

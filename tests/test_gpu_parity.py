@@ -477,6 +477,24 @@ def test_more_than_2_to_32_points(ek, orc):
     ek.empty_cache()
 
 
+def _csv_wet_bulb_check(got, want, t_method, what):
+    """The reference's own assertion for its wet-bulb files (tests/thermo/test_thermo.py:802-809, 842-849 there):
+    allclose(rtol=1e-3, atol=0, equal_nan=True).  Newton and direct: exactly that.  Bisection: on the exactly
+    saturated low-pressure rows of that table the sign of a mathematically zero residual decides between a
+    number and NaN (the reference's own fp32 and fp64 outputs differ there), so NaN-pattern differences are
+    counted against a budget of 2 % of the rows (largest seen: recorded by the ledger) instead of 0."""
+    from _compare import _record
+
+    if t_method != "bisect":
+        assert np.allclose(got, want, rtol=1e-3, atol=0, equal_nan=True), what
+        return
+    mism = np.isfinite(got) != np.isfinite(want)
+    _record(what, "bisect (reference CSV): NaN-pattern differences on saturated rows", mism.sum(), 0.02 * mism.size, mism.size)
+    assert mism.sum() <= 0.02 * mism.size, f"{what}: {mism.sum()} NaN-pattern differences"
+    ok = ~mism
+    assert np.allclose(got[ok], want[ok], rtol=1e-3, atol=0, equal_nan=True), what
+
+
 def test_reference_csv_fixtures_through_the_product(ek):
     """The checks the reference's own test module makes against its tests/data/*.csv, with its tolerances
     (default allclose; rtol=1e-3 for the wet-bulb files), made through `thermo.array.<name>` on the GPU."""
@@ -507,20 +525,13 @@ def test_reference_csv_fixtures_through_the_product(ek):
             for hum, arg in (("td", td), ("q", q)):
                 f = T.wet_bulb_temperature_from_dewpoint if hum == "td" else T.wet_bulb_temperature_from_specific_humidity
                 got = f(t, arg, p, ept_method=m, t_method=tm)
-                want = c[f"t_wet.{m}_{tm}_{hum}"]
-                # saturated low-pressure rows: bisection turns NaN on a rounding-level sign flip
-                ok = np.isfinite(got) & np.isfinite(want)
-                assert (np.isfinite(got) != np.isfinite(want)).mean() < 0.03
-                assert np.allclose(got[ok], want[ok], rtol=1e-3, atol=0)
+                _csv_wet_bulb_check(got, c[f"t_wet.{m}_{tm}_{hum}"], tm, f"t_wet.{m}_{tm}_{hum}")
         for tm in ("direct", "bisect", "newton"):
             for hum, arg in (("td", td), ("q", q)):
                 f = (T.wet_bulb_potential_temperature_from_dewpoint if hum == "td"
                      else T.wet_bulb_potential_temperature_from_specific_humidity)
                 got = f(t, arg, p, ept_method=m, t_method=tm)
-                want = c[f"t_wetpt.{m}_{tm}_{hum}"]
-                ok = np.isfinite(got) & np.isfinite(want)
-                assert (np.isfinite(got) != np.isfinite(want)).mean() < 0.03
-                assert np.allclose(got[ok], want[ok], rtol=1e-3, atol=0)
+                _csv_wet_bulb_check(got, c[f"t_wetpt.{m}_{tm}_{hum}"], tm, f"t_wetpt.{m}_{tm}_{hum}")
 
 
 def test_device_array_api(ek):

@@ -128,44 +128,20 @@ def test_lane_streams_are_bounded_and_releasable(ek):
 
 
 # ---- DLPack with a foreign ROCm library -----------------------------------------------------------------
-@pytest.fixture(scope="module")
-def torch_rocm(ek):
-    torch = pytest.importorskip("torch")
-    if not torch.cuda.is_available():
-        pytest.skip("torch sees no ROCm device")
-    return torch
-
-
-def test_dlpack_foreign_producer_and_consumer_zero_copy(ek, torch_rocm):
+def test_dlpack_with_torch_as_foreign_producer_and_consumer(ek):
     """torch tensor -> ek.from_dlpack (zero copy) -> HIP kernel -> torch.from_dlpack(result) (zero copy), with the
-    stream hand-over of the array-API protocol in both directions.  This is the route the reference's
-    `array_namespace(*inputs)` dispatch (thermo/array/thermo.py:826) offers to Torch users."""
-    torch = torch_rocm
-    t, q, p = _fields(4, 1 << 20)
-    want = _device_path(ek, "relative_humidity_from_specific_humidity", (t, q, p))[0]
-    dev = torch.device("cuda", ek.current_device())
-    side = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(side):  # producer work on a non-default torch stream, still in flight at hand-over
-        tt = torch.from_numpy(t).to(dev, non_blocking=False) * 1.0
-        tq = torch.from_numpy(q).to(dev) * 1.0
-        tp = torch.from_numpy(p).to(dev) * 1.0
-        dt_, dq_, dp_ = (ek.from_dlpack(x) for x in (tt, tq, tp))
-    assert dt_.ptr == tt.data_ptr() and dq_.ptr == tq.data_ptr()  # zero copy in
-    assert dt_.shape == t.shape and dt_.dtype == np.float32
-    rh = ek.thermo.relative_humidity_from_specific_humidity(dt_, dq_, dp_)
-    back = torch.from_dlpack(rh)  # consumer passes ITS current stream: ordered after our kernel
-    assert back.data_ptr() == rh.ptr and tuple(back.shape) == t.shape  # zero copy out
-    doubled = (back * 2.0).cpu().numpy()
-    assert np.array_equal(doubled, want * 2.0)
-    assert np.array_equal(back.cpu().numpy(), want)
-    del back, rh, dt_, dq_, dp_
+    stream hand-over of the array-API protocol in both directions: the route the reference's
+    `array_namespace(*inputs)` dispatch (thermo/array/thermo.py:826) offers to Torch users.  Runs in a child
+    process (tests/_dlpack_torch_child.py) that imports torch BEFORE libekm_thermo.so is loaded: both link
+    libamdhip64.so.7, and the process must use one HIP runtime for the two libraries to share pointers and
+    streams (torch loaded second finds no device in this image)."""
+    import subprocess
+    import sys
 
-
-def test_dlpack_rejects_non_rocm_and_non_float(ek, torch_rocm):
-    torch = torch_rocm
-    with pytest.raises(TypeError):
-        ek.from_dlpack(torch.ones(4))  # CPU tensor
-    with pytest.raises(TypeError):
-        ek.from_dlpack(torch.ones(4, dtype=torch.int32, device="cuda"))
-    with pytest.raises(ValueError):
-        ek.from_dlpack(torch.ones(4, 4, device="cuda").t())  # not C-contiguous
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dlpack_torch_child.py")
+    r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-2000:])
+    if r.returncode == 77:
+        pytest.skip(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "torch unavailable")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "DLPACK_TORCH_OK" in r.stdout
