@@ -191,6 +191,9 @@ struct OpTable<OpWbptFromQ<EPT_IFS, T_BISECT>> : BisectIfsTable {
 // thermo.py:1678-1707
 EKM_OP(OpGasConstant, 1, 1, y[0] = T(k::Rd) + T(k::Rv - k::Rd) * x[0];)
 
+// wind/array/wind.py:192-222: hydrostatic vertical velocity w = (-Rd/g) * (omega*t/p)
+EKM_OP(OpWFromOmega, 3, 1, y[0] = T(-k::Rd / k::g) * m_div(x[0] * x[1], x[2]);)
+
 // Fused compositions: one read of (t, q, p),
 // one write per output field.
 // P3: es = saturation_vapour_pressure(t); td = dewpoint_from_specific_humidity(q, p);

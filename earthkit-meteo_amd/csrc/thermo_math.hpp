@@ -30,6 +30,7 @@ namespace ekm {
 namespace k {
 constexpr double Rd = 287.0597;
 constexpr double Rv = 461.51;
+constexpr double g = 9.80665;  // constants/constants.py:53
 constexpr double c_pd = 1004.79;
 constexpr double Lv = 2.5008e6;
 constexpr double kappa = 0.285691;
@@ -217,6 +218,14 @@ EKM_HD double m_pow(double x, double y) { return pow(x, y); }
 template <class T>
 EKM_HD T m_sq(T x) {
   return x * x;
+}
+
+// min(|a|, |b|, |c|), NaN operands ignored (one v_min3_f32 with abs modifiers on the device)
+EKM_HD float m_min3abs(float a, float b, float c) {
+  return __builtin_fminf(__builtin_fminf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c));
+}
+EKM_HD double m_min3abs(double a, double b, double c) {
+  return __builtin_fmin(__builtin_fmin(__builtin_fabs(a), __builtin_fabs(b)), __builtin_fabs(c));
 }
 
 // numpy.sign: -1 / 0 / +1, NaN stays NaN
@@ -623,9 +632,9 @@ EKM_HD Regime davies_regime(T c_te, T cd, T p, const TeExact& te_exact) {
   r.r3 = T(0.4) <= c_te && c_te < T(1);
   r.r4 = c_te < T(0.4);
   if constexpr (TeExact::have && sizeof(T) == 4) {
-    const T tau = T(kTieBand);
-    const T d1 = cd - T(1), d2 = c_te - T(1), d3 = c_te - T(0.4);
-    const bool tie = (d1 < tau && d1 > -tau) || (d2 < tau && d2 > -tau) || (d3 < T(0.4) * tau && d3 > T(-0.4) * tau);
+    // one v_min3 over |c_te/D - 1|, |c_te - 1|, |c_te/0.4 - 1| and one compare (NaN compares false: no tie)
+    const T d1 = cd - T(1), d2 = c_te - T(1), d3 = c_te * T(2.5) - T(1);
+    const bool tie = m_min3abs(d1, d2, d3) < T(kTieBand);
     if (EKM_ANY(tie)) {
       const double te = te_exact();
       const double c = m_exp2(double(float(k::lambda)) * m_log2(double(273.16f) * m_rcp(te)));

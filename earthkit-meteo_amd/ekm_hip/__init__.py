@@ -8,7 +8,7 @@ Hand-written HIP kernels for gfx950 behind a C ABI (include/ekm_thermo.h),
 called through ctypes.  No PyTorch / CuPy / Triton on the product path and no
 CPU fallback: a missing library or GPU raises.
 """
-from . import thermo, vertical  # noqa: F401
+from . import thermo, vertical, wind  # noqa: F401
 from ._ffi import EkmError, EkmLibraryError  # noqa: F401
 from .device import (  # noqa: F401
     DeviceArray,

@@ -2,6 +2,8 @@
 fp64: 1e-6 relative (measured ~1e-15).  fp32: the reference's own fp32 tolerances for this function
 (tests/vertical/test_array_vertical.py:192-198 there): p 1e-4 relative, delta atol 1e-6 rtol 1e-5,
 alpha atol 1e-4 rtol 1e-5 (alpha = 1 - x*delta cancels to ~1 % of its terms)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -163,3 +165,25 @@ def test_example_model_level_postprocessing(ek):
     rh, h = mod.main(nlat=37, nlon=72)
     assert rh.shape == (137, 37, 72) and np.isfinite(rh[40:]).all() and np.isfinite(h).all()
     assert (np.diff(h, axis=0) < 0).all()  # height decreases from the model top to the surface
+
+
+# ---- wind.w_from_omega (the free rider on the map skeleton) ------------------------
+@pytest.mark.parametrize("tag,rtol", [("f64", 1e-6), ("f32", 1e-4)])
+def test_w_from_omega_vs_reference_vectors(ek, tag, rtol):
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wind_golden.npz"))
+    o, t, p, pl = (g[f"{tag}.in.{k}"] for k in ("omega", "t", "p", "plev"))
+    W = ek.wind.array.w_from_omega
+    cases = ((W(o, t, p), "field"), (W(o, t, pl[:, None]), "levmajor"), (W(o, t, o.dtype.type(85000.0)), "scalar_p"))
+    for got, key in cases:
+        want = g[f"{tag}.out.{key}"]
+        assert got.dtype == want.dtype and got.shape == want.shape, key
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isinf(got), np.isinf(want)), key
+        fin = np.isfinite(want) & (want != 0)
+        assert np.max(np.abs(got[fin] - want[fin]) / np.abs(want[fin])) <= rtol, key
+    # the reference's own known answer (tests/wind/test_wind.py:183-194 there), lists in, fp64 out
+    got = ek.wind.w_from_omega([1.2, 21.3], [285.6, 261.1], [100000.0, 85000.0])
+    assert got.dtype == np.float64 and np.allclose(got, [-0.1003208031, -1.9152219066])
+    # device-resident: DeviceArray in -> DeviceArray out, level vector kept as such
+    d = [ek.to_device(x) for x in (o, t, pl[:, None])]
+    dev = W(*d)
+    assert isinstance(dev, ek.DeviceArray) and np.array_equal(dev.to_host(), cases[1][0], equal_nan=True)

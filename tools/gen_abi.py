@@ -65,6 +65,8 @@ OPS = [
     ("wet_bulb_potential_temperature_from_dewpoint", "OpWbptFromTd", ["t", "td", "p"], ["out"], [EPT, TM3], False, "1593-1634,1047-1053", "wbpt"),
     ("wet_bulb_potential_temperature_from_specific_humidity", "OpWbptFromQ", ["t", "q", "p"], ["out"], [EPT, TM3], False, "1637-1675,1047-1053", "wbpt"),
     ("specific_gas_constant", "OpGasConstant", ["q"], ["out"], [], False, "1678-1707", "basic"),
+    # SURVEY.md 8f rank 4 names this free rider on the map skeleton (the only non-thermo entry point)
+    ("w_from_omega", "OpWFromOmega", ["omega", "t", "p"], ["out"], [], False, "wind/array/wind.py:192-222", "wind"),
     ("pipeline_svp_td_rh", "OpPipelineSvpTdRh", ["t", "q", "p"], ["es", "td", "rh"], [], False,
      "235-279 + 702-735 + 524-556 fused (SURVEY.md 8a row a13, P3)", "pipeline"),
     ("pipeline_full", "OpPipelineFull", ["t", "q", "p"], ["theta", "es", "rh", "td", "theta_e", "tw"], [], False,
@@ -272,7 +274,7 @@ def proto(name, ins, outs, ints, has_eps, tag, ctype, prefix="ekm_"):
 
 
 def cite(ref):
-    return ref if ("SURVEY" in ref) else f"thermo/array/thermo.py:{ref}"
+    return ref if ("SURVEY" in ref or ".py:" in ref.split(";")[0].split(",")[0] and not ref[0].isdigit()) else f"thermo/array/thermo.py:{ref}"
 
 
 def gen_header():

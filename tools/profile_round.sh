@@ -1,0 +1,28 @@
+#!/bin/bash
+# The rocprofv3 evidence of one round, produced on the GPU box (through gpurun) and summarised into profiles/:
+#   tools/profile_round.sh r02
+# kernel-trace + stats, FETCH_SIZE, WRITE_SIZE (separate passes) for the bench default (P5), P3, wet-bulb, bisect,
+# the level / hybrid pressure modes; SQ VALU counters for the VALU-bound kernels.
+set -u
+R=${1:?round tag}
+G=gpurun_out/prof_$R
+mkdir -p "$G" profiles
+run() {  # name  summarize-key  bench args...
+  local name=$1 key=$2; shift 2
+  tools/profile_gpu.sh "$G/$name" "$@" > "$G/$name.log" 2>&1 || { echo "profile $name failed ($?)"; return 1; }
+  python3 tools/summarize_profile.py "$G/$name" "profiles/${R}_$name" "$key" > /dev/null && echo "profiled $name"
+}
+run full            full:field:f32:137
+run p3              p3:field:f32:137            --workload p3
+run wetbulb         wetbulb:field:f32:137       --workload wetbulb
+run bisect          wetbulb_bisect:field:f32:137 --workload wetbulb_bisect
+run full_level      full:level:f32:137          --pmode level
+run p3_level        p3:level:f32:137            --workload p3 --pmode level
+run p3_hybrid       p3:hybrid:f32:137           --workload p3 --pmode hybrid
+run theta_hybrid    theta:hybrid:f32:137        --workload theta --pmode hybrid
+run geopotential    geopotential:hybrid:f32:137 --workload geopotential
+for wl in full wetbulb wetbulb_bisect p3; do
+  tools/profile_valu.sh "$G/valu_$wl" --workload $wl > "$G/valu_$wl.log" 2>&1 && python3 tools/summarize_valu.py "$G/valu_$wl" $wl "profiles/${R}_valu_counters.json"
+done
+tools/profile_valu.sh "$G/valu_wetbulb_level" --workload wetbulb --pmode level > /dev/null 2>&1 && python3 tools/summarize_valu.py "$G/valu_wetbulb_level" wetbulb_level "profiles/${R}_valu_counters.json"
+mkdir -p gpurun_out/profiles_$R && cp profiles/${R}_* profiles/traffic_latest.json gpurun_out/profiles_$R/
