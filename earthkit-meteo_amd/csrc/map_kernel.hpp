@@ -300,18 +300,19 @@ __global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, 
 // 3-D grid: blockIdx.x walks the horizontal tiles of ONE level inside a band of `gridDim.x` tiles (in order, so
 // every stream is still one moving window), blockIdx.y selects the level (group), blockIdx.z the band.  The
 // dispatcher issues x fastest, then y, then z: all levels of a band are processed before the next band starts.
-// PM_LEVEL uses one band (the whole level); PM_HYBRID uses bands of 4 MiB of surface pressure, so that the
+// PM_LEVEL uses one band (the whole level); PM_HYBRID uses bands of 8 MiB of surface pressure, so that the
 // band's sp chunk is still in the XCD's L2 when the next level re-reads it (each XCD sees every 8th tile:
-// 512 KiB of sp per band against 4 MiB of L2), instead of coming back from the Infinity Cache / HBM once per
+// 1 MiB of sp per band against 4 MiB of L2), instead of coming back from the Infinity Cache / HBM once per
 // level (26 MB x 137 levels: measured 1.10x the algorithmic traffic in round 1).
 // Everything that depends on the level alone is wave-uniform:
 //  * PM_LEVEL: the pressure of the level is one scalar load; sub-expressions of pressure alone (log2(p/p0),
 //    (p0/p)^kappa, (p/p0)^kappa, 1/D(p), ...) are computed once per 16-B chunk instead of once per point, and
 //    p costs no HBM traffic.  A scalar operand is the one-level case.
 //  * PM_HYBRID (EKM_HYBRID_FULL): p = ph_k + 0.5*(ph_k+1 - ph_k), ph_h = A_h + B_h*sp (vertical.py:670,708) from
-//    the lane's surface-pressure chunk; the pressure field itself never exists.  (A workgroup can also walk
-//    `lev_per_wg` > 1 consecutive levels of its tile with sp and ph_k+1 kept in registers; measured slower
-//    than 1 because every stream then has lev_per_wg windows open: profiles/r02_sweep_hybrid.txt.)
+//    the lane's surface-pressure chunk; the pressure field itself never exists.  A workgroup can also walk
+//    `lev_per_wg` > 1 consecutive levels of its tile with sp and ph_k+1 kept in registers: faster for a
+//    one-in one-out op, slower once several streams are open, each then with lev_per_wg windows
+//    (profiles/r02_sweep_hybrid.txt).
 // No per-lane position bookkeeping, no integer division, no LDS: a tile never straddles levels.
 enum { PM_LEVEL = 0, PM_HYBRID = 1 };
 
@@ -425,8 +426,8 @@ int device_cus(int dev);            // CU count of device `dev` (cached), <0 on 
 int use_device(int dev);            // hipSetDevice with error capture
 int tuning_tiles_per_block();
 int tuning_unroll();
-int tuning_lev_per_wg();    // EKM_HYBRID_FULL: consecutive levels one workgroup walks (EKM_LEV_PER_WG, default 1)
-int tuning_hybrid_band_bytes();  // EKM_HYBRID_FULL: bytes of surface pressure per band (EKM_HYBRID_BAND_KB, default 4096 KiB)
+int tuning_lev_per_wg();    // EKM_HYBRID_FULL: consecutive levels one workgroup walks (EKM_LEV_PER_WG, default 0 = by stream count)
+int tuning_hybrid_band_bytes();  // EKM_HYBRID_FULL: bytes of surface pressure per band (EKM_HYBRID_BAND_KB, default 8192 KiB)
 int tuning_table_tiles();   // tiles per workgroup for ops that build an LDS table (EKM_TABLE_TILES, default 16)
 
 constexpr unsigned kMaxLdsBytes = 64 * 1024;
@@ -541,7 +542,10 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
       la.last = pm == EKM_SCALAR ? 0u : a.len[NIN - 1] - 1u;
       if (pm == EKM_SCALAR) inner = n < (1ull << 30) ? n : (1ull << 30);  // one "level" of any convenient length
       const unsigned long long nlev = (n + inner - 1) / inner;
-      la.lev_per_wg = pm == EKM_HYBRID_FULL ? (unsigned)tuning_lev_per_wg() : 1u;
+      // hybrid: 0 = auto: a one-in one-out op (theta: 8 B/pt) gains from walking 4 levels per workgroup with sp and
+      // the shared half-level pressure in registers (1.29 -> 1.16 ms); with more streams open it loses (P3 3.01 -> 3.28 ms)
+      la.lev_per_wg = 1u;
+      if (pm == EKM_HYBRID_FULL) la.lev_per_wg = tuning_lev_per_wg() > 0 ? (unsigned)tuning_lev_per_wg() : (NIN - 1 + NOUT <= 2 ? 4u : 1u);
       if (la.lev_per_wg > nlev) la.lev_per_wg = (unsigned)nlev;
       const unsigned long long gy = (nlev + la.lev_per_wg - 1) / la.lev_per_wg;
       // shapes this kernel is not meant for go to map_bcast: rows longer than 32-bit columns, more level

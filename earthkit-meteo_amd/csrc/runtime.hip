@@ -90,18 +90,30 @@ static int env_int(const char* name, int dflt, int lo, int hi) {
   const long x = strtol(v, nullptr, 10);
   return x < lo ? lo : (x > hi ? hi : (int)x);
 }
-int tuning_lev_per_wg() {
-  static const int v = env_int("EKM_LEV_PER_WG", 1, 1, 1024);
+// secondary launch parameters: environment at first use, ekm_set_tuning_param afterwards
+struct Param {
+  const char* name;
+  const char* env;
+  int dflt, lo, hi;
+  std::atomic<int> value{-1};
+};
+static Param g_params[] = {
+    {"lev_per_wg", "EKM_LEV_PER_WG", 0, 0, 1024},
+    {"hybrid_band_kb", "EKM_HYBRID_BAND_KB", 8192, 4, 1 << 20},
+    {"table_tiles", "EKM_TABLE_TILES", 16, 1, 4096},
+};
+static int param(int i) {
+  int v = g_params[i].value.load(std::memory_order_relaxed);
+  if (v < 0) {
+    v = env_int(g_params[i].env, g_params[i].dflt, g_params[i].lo, g_params[i].hi);
+    g_params[i].value.store(v, std::memory_order_relaxed);
+  }
   return v;
 }
-int tuning_hybrid_band_bytes() {
-  static const int v = env_int("EKM_HYBRID_BAND_KB", 4096, 4, 1 << 20);
-  return v * 1024;
-}
-int tuning_table_tiles() {
-  static const int v = env_int("EKM_TABLE_TILES", 16, 1, 4096);
-  return v;
-}
+int tuning_lev_per_wg() { return param(0); }
+int tuning_hybrid_band_bytes() { return param(1) * 1024; }
+int tuning_table_tiles() { return param(2); }
+
 
 // ---- synthetic atmosphere on the device (SURVEY.md 8d distribution) ---------
 // Counter-based: every value is a pure function of (seed, global point index),
@@ -407,6 +419,19 @@ int ekm_get_tuning(int* tiles_per_block, int* unroll) {
   if (tiles_per_block) *tiles_per_block = g_tiles_per_block.load();
   if (unroll) *unroll = g_unroll.load();
   return EKM_OK;
+}
+
+int ekm_set_tuning_param(const char* name, int value) {
+  if (!name) return set_error(EKM_ERR_ARG, "set_tuning_param: null name");
+  for (Param& p : g_params) {
+    if (strcmp(p.name, name) == 0) {
+      if (value < p.lo || value > p.hi)
+        return set_error(EKM_ERR_ARG, "set_tuning_param: %s must be in [%d, %d]", name, p.lo, p.hi);
+      p.value.store(value);
+      return EKM_OK;
+    }
+  }
+  return set_error(EKM_ERR_ARG, "set_tuning_param: unknown parameter '%s' (lev_per_wg, hybrid_band_kb, table_tiles)", name);
 }
 
 int ekm_synth_fill_f32(int dev, void* stream, float* t, float* q, float* p, uint64_t first, size_t n, uint64_t inner,

@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--skew", default="0", help="comma list: byte offset added to the k-th array's base (k*skew)")
+    ap.add_argument("--params", default="", help="secondary parameters to sweep, e.g. hybrid_band_kb=512:4096:32768,"
+                                                   "lev_per_wg=1:2 (ekm_set_tuning_param); the cross product is run")
     a = ap.parse_args()
 
     libs = {}
@@ -79,23 +81,49 @@ def main():
     chk(base.ekm_event_create(dev, C.byref(ev0)))
     chk(base.ekm_event_create(dev, C.byref(ev1)))
     F = _ffi.Operand
-    ops = {"t": F(t, 0, 0, 0, 0), "q": F(q, 0, 0, 0, 0),
-           "p": F(p, 0, 0, 0, 0) if a.pmode == "field" else F(pl, 2, 0, a.levels, INNER)}
+    hyb = None
+    if a.pmode == "hybrid" or "geopotential" in a.workloads:
+        import numpy as np
 
-    configs = [(ln, int(b), int(u), w, sk) for ln in libs for b in a.tiles.split(",") for u in a.unroll.split(",")
-               for w in a.workloads.split(",") for sk in skews]
+        g = np.load(os.path.join(ROOT, "tests", "golden", "vertical_golden.npz"))
+        dt = np.float32 if a.dtype == "f32" else np.float64
+        A, B = (g[f"coef.137.{k}"][137 - a.levels:].astype(dt) for k in "AB")
+        sp = (101325.0 * (1.0 - 0.35 * np.random.default_rng(1).random(INNER) ** 3)).astype(dt)
+        zs = np.maximum(0.0, (101325.0 - sp.astype(np.float64)) / 1.2).astype(dt)
+        hyb = []
+        for arr in (A, B, sp, zs):
+            ptr = dmalloc(arr.nbytes)
+            chk(base.ekm_h2d(dev, ptr, arr.ctypes.data, arr.nbytes, None))
+            hyb.append(ptr)
+        chk(base.ekm_sync(dev))
+    ops = {"t": F(t, 0, 0, 0, 0), "q": F(q, 0, 0, 0, 0),
+           "p": F(p, 0, 0, 0, 0) if a.pmode == "field" else (
+               F(pl, 2, 0, a.levels, INNER) if a.pmode == "level" else F(hyb[2], 4, 0, a.levels, INNER, hyb[0], hyb[1]))}
+    W["geopotential"] = ("geopotential_on_hybrid_levels", "", (), 1, 12)
+    pnames = [kv.split("=")[0] for kv in a.params.split(",") if kv]
+    pvals = [[int(v) for v in kv.split("=")[1].split(":")] for kv in a.params.split(",") if kv]
+    import itertools
+
+    psets = list(itertools.product(*pvals)) if pnames else [()]
+
+    configs = [(ln, int(b), int(u), w, sk, ps) for ln in libs for b in a.tiles.split(",") for u in a.unroll.split(",")
+               for w in a.workloads.split(",") for sk in skews for ps in psets]
     times = {c: [] for c in configs}
     for rnd in range(a.rounds + 1):  # round 0 = warm-up
         for c in configs:
-            ln, b, u, w, sk = c
+            ln, b, u, w, sk, ps = c
             lib = libs[ln]
             entry, which, ints, nout, bpp = W[w]
             chk(lib.ekm_set_tuning(b, u))
+            for pn, pv in zip(pnames, ps):
+                chk(lib.ekm_set_tuning_param(pn.encode(), pv))
             fn = getattr(lib, f"ekm_{entry}_{a.dtype}")
             sops = {"t": F(t, 0, 0, 0, 0), "q": F(q + sk, 0, 0, 0, 0),
                     "p": F(p + 2 * sk, 0, 0, 0, 0) if a.pmode == "field" else ops["p"]}
             cargs = [dev, None] + [C.byref(sops[k]) for k in which] + list(ints) + \
                 [o + (3 + i) * sk for i, o in enumerate(outs[:nout])] + [n]
+            if w == "geopotential":
+                cargs = [dev, None, hyb[0], hyb[1], hyb[2], hyb[3], t, q, INNER, a.levels, 1, 0.6931471805599453, 1, outs[0]]
             chk(fn(*cargs))
             chk(base.ekm_event_record(dev, ev0, None))
             for _ in range(a.steps):
@@ -108,12 +136,12 @@ def main():
                 times[c].append(ms.value / a.steps)
     rows = []
     for c in configs:
-        ln, b, u, w, sk = c
-        bpp = (W[w][4] - (4 if a.pmode == "level" and "p" in W[w][1] else 0)) * isz // 4
+        ln, b, u, w, sk, ps = c
+        bpp = (W[w][4] - (4 if a.pmode in ("level", "hybrid") and "p" in W[w][1] else 0)) * isz // 4
         med, mn = statistics.median(times[c]), min(times[c])
-        rows.append(dict(lib=ln, tiles=b, unroll=u, workload=w, skew=sk, med_ms=round(med, 4), min_ms=round(mn, 4),
+        rows.append(dict(lib=ln, tiles=b, unroll=u, workload=w, skew=sk, params=dict(zip(pnames, ps)), med_ms=round(med, 4), min_ms=round(mn, 4),
                          gbs_med=round(bpp * n / med / 1e6, 1), frac=round(bpp * n / med / 1e6 / 8000, 4)))
-        print(f"{ln:28s} tiles={b:<5d} u={u} skew={sk:<8d} {w:15s} med {med:8.4f} ms  min {mn:8.4f} ms  {rows[-1]['gbs_med']:8.1f} GB/s"
+        print(f"{ln:28s} tiles={b:<5d} u={u} skew={sk:<8d} {dict(zip(pnames, ps))!s:36s} {w:15s} med {med:8.4f} ms  min {mn:8.4f} ms  {rows[-1]['gbs_med']:8.1f} GB/s"
               f"  {rows[-1]['frac'] * 100:5.1f}%", flush=True)
     if a.out:
         with open(a.out, "w") as f:
