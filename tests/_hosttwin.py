@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PATH = os.path.join(ROOT, "tests", "_build", "libekm_hosttwin.so")
+PATH = os.environ.get("EKM_HOSTTWIN_LIB") or os.path.join(ROOT, "tests", "_build", "libekm_hosttwin.so")
+ASAN_PATH = os.path.join(ROOT, "tests", "_build", "libekm_hosttwin_asan.so")
 
 import sys  # noqa: E402
 
