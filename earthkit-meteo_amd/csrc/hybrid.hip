@@ -134,22 +134,28 @@ __global__ __launch_bounds__(kThreads) void any_le(const T* __restrict__ sp, uns
 enum { GEO_THICKNESS = 0, GEO_GEOPOTENTIAL = 1, GEO_H_GEOM_SEA = 2, GEO_H_GP_SEA = 3, GEO_H_GEOM_GROUND = 4,
        GEO_H_GP_GROUND = 5 };
 
-template <class T>
-__global__ __launch_bounds__(kThreads) void geopotential_columns(const T* __restrict__ A, const T* __restrict__ B,
+// VEC: every pointer is 16-B aligned and npts is a multiple of the vector width, so each active lane moves whole
+// 16-B chunks and the level loop is straight-line code (no per-lane branch around any load or store).
+#ifndef EKM_GEO_THREADS
+#define EKM_GEO_THREADS 256
+#endif
+constexpr int kGeoThreads = EKM_GEO_THREADS;
+
+template <class T, bool VEC>
+__global__ __launch_bounds__(kGeoThreads) void geopotential_columns(const T* __restrict__ A, const T* __restrict__ B,
                                                                 const T* __restrict__ sp, const T* __restrict__ zs,
                                                                 const T* __restrict__ t, const T* __restrict__ q,
                                                                 unsigned long long npts, unsigned nfull,
-                                                                int top_is_zero, T alpha_top, int mode,
-                                                                T* __restrict__ out, int vec_ok) {
+                                                                unsigned k_lo, unsigned k_hi, int top_is_zero,
+                                                                T alpha_top, int mode, T* __restrict__ out) {
   constexpr int V = VecOf<T>::N;
   typedef typename VecOf<T>::type Vec;
-  const unsigned long long i0 = ((unsigned long long)blockIdx.x * kThreads + threadIdx.x) * V;
+  const unsigned long long i0 = ((unsigned long long)blockIdx.x * kGeoThreads + threadIdx.x) * V;
   if (i0 >= npts) return;
-  const bool whole = vec_ok && (i0 + V <= npts);
   auto get = [&](const T* base, unsigned row) {
     const T* src = base + (unsigned long long)row * npts + i0;
     Vec v;
-    if (whole) {
+    if (VEC) {
       v = ld_stream<T>(src);
     } else {
 #pragma unroll
@@ -171,38 +177,31 @@ __global__ __launch_bounds__(kThreads) void geopotential_columns(const T* __rest
     }
   }
 
+  // This launch walks the levels [k_lo, k_hi) bottom-up.  The column can be cut into chunks of `geo_chunk_levels`
+  // levels, one launch each from the surface upward (fewer of the 3 x 137 row streams open at once).  Measured in
+  // one process (profiles/r02_sweep_geopotential.txt): no gain -- 1.80 ms whole, 1.95 ms in chunks of 35 -- and
+  // neither from a register ring prefetching the next 2-5 levels nor from 128/512/1024-thread workgroups; what moves
+  // this kernel is where its 3.55-GB fields land in physical memory (1.80 vs 2.05-2.15 ms between processes on the
+  // same device).  So the default is one launch; the chunked path stays (and is tested) for very tall columns.
+  // The only state that crosses a chunk boundary is the running sum `acc` (the half-level pressure is recomputed
+  // from A, B, sp): it travels in the output row just above the chunk (row k_lo - 1), which the next launch reads
+  // before it overwrites it -- same lane, program order -- so no workspace is needed and nothing is allocated.
   Vec acc;
 #pragma unroll
   for (int j = 0; j < V; ++j) acc[j] = T(0);
-  Vec phn = A[nfull] + B[nfull] * s;  // lower half level of the current layer
-  // The walk is a serial chain of 137 row visits 26 MB apart.  The t, q rows of the next EKM_GEO_PREFETCH
-  // levels can be kept in flight in a register ring (static slots: no register that is still being loaded is
-  // ever moved); measured in one process with depth 1, 2, 3, 5: 2.03 ms each (profiles/r02_sweep_geopotential.txt)
-  // -- the scan is bound by its 411 concurrent row streams, not by load latency -- so the default stays 1.
-#ifndef EKM_GEO_PREFETCH
-#define EKM_GEO_PREFETCH 1
-#endif
-  constexpr int D = EKM_GEO_PREFETCH;
-  Vec tb[D], qb[D];  // slot d holds the row (base - 1 - d) of the current group of D levels
+  if (k_hi < nfull) {  // not the bottom chunk: pick up the running sum left in our first output row
+    const T* src = out + (unsigned long long)(k_hi - 1) * npts + i0;
+    if (VEC) {
+      acc = *reinterpret_cast<const Vec*>(src);
+    } else {
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
-    if ((unsigned)d < nfull) {
-      tb[d] = get(t, nfull - 1 - d);
-      qb[d] = get(q, nfull - 1 - d);
+      for (int j = 0; j < V; ++j) acc[j] = (i0 + j < npts) ? src[j] : T(0);
     }
   }
-  for (int base = (int)nfull; base > 0; base -= D) {
-#pragma unroll
-   for (int d = 0; d < D; ++d) {  // static slot index: the ring never moves a register that is still in flight
-    const int kks = base - 1 - d;
-    if (kks < 0) break;
-    const unsigned kk = (unsigned)kks;
+  Vec phn = A[k_hi] + B[k_hi] * s;  // lower half level of the current layer
+  for (unsigned kk = k_hi; kk-- > k_lo;) {
     const Vec ph = A[kk] + B[kk] * s;
-    const Vec tk = tb[d], qk = qb[d];
-    if (kks >= D) {  // refill the slot with the row the next group will want from it
-      tb[d] = get(t, kk - D);
-      qb[d] = get(q, kk - D);
-    }
+    const Vec tk = get(t, kk), qk = get(q, kk);
     Vec o;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
@@ -227,7 +226,7 @@ __global__ __launch_bounds__(kThreads) void geopotential_columns(const T* __rest
       o[j] = r;
     }
     T* dst = out + (unsigned long long)kk * npts + i0;
-    if (whole) {
+    if (VEC) {
       st_stream<T>(dst, o);
     } else {
 #pragma unroll
@@ -235,7 +234,16 @@ __global__ __launch_bounds__(kThreads) void geopotential_columns(const T* __rest
         if (i0 + j < npts) dst[j] = o[j];
     }
     phn = ph;
-   }
+  }
+  if (k_lo > 0) {  // hand the running sum to the chunk above
+    T* dst = out + (unsigned long long)(k_lo - 1) * npts + i0;
+    if (VEC) {
+      *reinterpret_cast<Vec*>(dst) = acc;
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j)
+        if (i0 + j < npts) dst[j] = acc[j];
+    }
   }
 }
 
@@ -255,11 +263,23 @@ static int launch_geopotential(int dev, void* stream, const T* A, const T* B, co
   for (const void* ptr : {(const void*)sp, (const void*)zs, (const void*)t, (const void*)q, (const void*)out})
     if (ptr && reinterpret_cast<uintptr_t>(ptr) % 16) vec_ok = 0;
   const unsigned long long nchunk = (npts + V - 1) / V;
-  const unsigned long long grid = (nchunk + kThreads - 1) / kThreads;
+  const unsigned long long grid = (nchunk + kGeoThreads - 1) / kGeoThreads;
   if (grid > 0x7fffffffull) return set_error(EKM_ERR_ARG, "geopotential_on_hybrid_levels: too many columns");
-  hipLaunchKernelGGL((geopotential_columns<T>), dim3((unsigned)grid), dim3(kThreads), 0,
-                     static_cast<hipStream_t>(stream), A, B, sp, zs, t, q, (unsigned long long)npts, nfull, top_is_zero,
-                     alpha_top, mode, out, vec_ok);
+  // chunks of at most `geo_chunk_levels` levels, balanced, launched from the surface upward on the same stream
+  const unsigned maxc = (unsigned)tuning_geo_chunk_levels();
+  const unsigned nchunks = (nfull + maxc - 1) / maxc;
+  for (unsigned c = 0; c < nchunks; ++c) {
+    const unsigned k_hi = nfull - (unsigned)((unsigned long long)nfull * c / nchunks);
+    const unsigned k_lo = nfull - (unsigned)((unsigned long long)nfull * (c + 1) / nchunks);
+    if (vec_ok)
+      hipLaunchKernelGGL((geopotential_columns<T, true>), dim3((unsigned)grid), dim3(kGeoThreads), 0,
+                         static_cast<hipStream_t>(stream), A, B, sp, zs, t, q, (unsigned long long)npts, nfull, k_lo,
+                         k_hi, top_is_zero, alpha_top, mode, out);
+    else
+      hipLaunchKernelGGL((geopotential_columns<T, false>), dim3((unsigned)grid), dim3(kGeoThreads), 0,
+                         static_cast<hipStream_t>(stream), A, B, sp, zs, t, q, (unsigned long long)npts, nfull, k_lo,
+                         k_hi, top_is_zero, alpha_top, mode, out);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(EKM_ERR_HIP, "geopotential_columns launch: %s", hipGetErrorString(e));
   return EKM_OK;

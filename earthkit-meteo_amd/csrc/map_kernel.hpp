@@ -429,6 +429,7 @@ int tuning_unroll();
 int tuning_lev_per_wg();    // EKM_HYBRID_FULL: consecutive levels one workgroup walks (EKM_LEV_PER_WG, default 0 = by stream count)
 int tuning_hybrid_band_bytes();  // EKM_HYBRID_FULL: bytes of surface pressure per band (EKM_HYBRID_BAND_KB, default 8192 KiB)
 int tuning_table_tiles();   // tiles per workgroup for ops that build an LDS table (EKM_TABLE_TILES, default 16)
+int tuning_geo_chunk_levels();  // levels per launch of the geopotential column scan (EKM_GEO_CHUNK_LEVELS, default: all in one launch)
 
 constexpr unsigned kMaxLdsBytes = 64 * 1024;
 

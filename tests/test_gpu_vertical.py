@@ -187,3 +187,28 @@ def test_w_from_omega_vs_reference_vectors(ek, tag, rtol):
     d = [ek.to_device(x) for x in (o, t, pl[:, None])]
     dev = W(*d)
     assert isinstance(dev, ek.DeviceArray) and np.array_equal(dev.to_host(), cases[1][0], equal_nan=True)
+
+
+def test_geopotential_scan_in_level_chunks_equals_one_launch(ek):
+    """The column scan can be cut into launches of a few levels each; the running sum crosses a chunk boundary in the
+    output row above it (csrc/hybrid.hip).  Chunks of 3 and 5 levels must reproduce the single launch bit for bit."""
+    from ekm_hip import _ffi
+
+    rng = np.random.default_rng(3)
+    A, B = G["coef.137.A"][137 - 24:], G["coef.137.B"][137 - 24:]
+    npts = 4099  # ragged: the unaligned kernel variant too
+    sp = rng.uniform(60000.0, 104000.0, npts).astype(np.float32)
+    zs = rng.uniform(0.0, 3e4, npts).astype(np.float32)
+    t = rng.uniform(200.0, 300.0, (24, npts)).astype(np.float32)
+    q = rng.uniform(0.0, 0.02, (24, npts)).astype(np.float32)
+    lib = _ffi.lib()
+    try:
+        outs = []
+        for chunk in (1 << 20, 5, 3):
+            _ffi.check(lib.ekm_set_tuning_param(b"geo_chunk_levels", chunk))
+            outs.append(ek.vertical.geopotential_on_hybrid_levels(t, q, zs, A, B, sp))
+            outs.append(ek.vertical.geopotential_on_hybrid_levels(t[:, :4096], q[:, :4096], zs[:4096], A, B, sp[:4096]))
+    finally:
+        _ffi.check(lib.ekm_set_tuning_param(b"geo_chunk_levels", 1 << 20))
+    for k in (2, 4):
+        assert np.array_equal(outs[0], outs[k], equal_nan=True) and np.array_equal(outs[1], outs[k + 1], equal_nan=True)
