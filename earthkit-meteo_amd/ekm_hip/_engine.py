@@ -165,6 +165,7 @@ _streams = {}
 _streams_lock = threading.Lock()
 _MAX_LANES = 8            # slices in flight per GPU when memory allows (upload of one overlaps download of another)
 _MIN_SLICE_BYTES = 16 << 20  # do not cut finer than this: small copies waste PCIe bandwidth
+_BLOCK_OVERHEAD = (1 << 20) + 16 * (20 << 10)  # worst-case rounding + stagger padding of one device block
 
 
 def _lane_stream(dev, slot):
@@ -201,7 +202,7 @@ def stream_budget_bytes(dev):
     return min(budget, int(cap)) if cap else budget
 
 
-def plan_slices(rows, row_bytes, budget, max_lanes=_MAX_LANES, min_slice=_MIN_SLICE_BYTES):
+def plan_slices(rows, row_bytes, budget, max_lanes=_MAX_LANES, min_slice=_MIN_SLICE_BYTES, overhead=0):
     """How to stream `rows` leading-axis rows of `row_bytes` device bytes each (inputs + outputs) through a
     device working set of at most `budget` bytes: returns (lanes, nslices) -- `lanes` slices are in flight at
     a time, each lane recycling its device blocks from slice to slice, and
@@ -209,17 +210,18 @@ def plan_slices(rows, row_bytes, budget, max_lanes=_MAX_LANES, min_slice=_MIN_SL
       * everything fits: one slice per lane, up to `max_lanes` lanes, slices of at least `min_slice` bytes
         (small copies waste PCIe bandwidth; a small call is one slice);
       * it does not fit: as many lanes as the budget allows with slices of at least `min_slice` (8, 4), at
-        least two (double buffering) whatever the slice size; None if two single-row slices do not fit."""
+        least two (double buffering) whatever the slice size; None if two single-row slices do not fit.
+    `overhead`: device bytes every in-flight slice costs on top of its rows (allocator rounding and stagger)."""
     total = rows * row_bytes
     if total == 0:
         return 1, 1
-    if total <= budget:
-        lanes = int(max(1, min(max_lanes, rows, total // min_slice)))
+    lanes = int(max(1, min(max_lanes, rows, total // min_slice)))
+    if total + lanes * overhead <= budget:
         return lanes, lanes
     for lanes in (8, 4, 2):
         if lanes > max(max_lanes, 2) or lanes > rows:
             continue
-        rows_per = (budget // lanes) // row_bytes
+        rows_per = max(0, budget // lanes - overhead) // row_bytes
         if rows_per < 1 or (lanes > 2 and rows_per * row_bytes < min_slice):
             continue
         return lanes, -(-rows // rows_per)
@@ -257,7 +259,9 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
     blocks = [b for b in leading_axis_bounds(shape[0], len(devs)) if b[1] > b[0]]
     plans = []
     for dev, (lo, hi) in zip(devs, blocks):
-        pl = plan_slices(hi - lo, max(row_bytes, 1), stream_budget_bytes(dev))
+        # every device block of a slice is rounded up to 1 MiB and carries the stagger padding (device._Allocation)
+        nblocks = sum(spans) + nout
+        pl = plan_slices(hi - lo, max(row_bytes, 1), stream_budget_bytes(dev), overhead=nblocks * _BLOCK_OVERHEAD)
         if pl is None:
             raise _ffi.EkmError(f"{name}: one leading-axis row needs {row_bytes} B on the device, two do not fit the "
                                 f"streaming budget of {stream_budget_bytes(dev)} B on device {dev}")

@@ -7,6 +7,7 @@ return DeviceArrays, so a pipeline of calls never crosses PCIe (one
 HBM time).  NumPy inputs are uploaded, computed on and downloaded per call.
 """
 import ctypes as C
+import itertools
 import os
 import threading
 
@@ -192,6 +193,10 @@ class _BlockCache:
 
 
 _cache = _BlockCache()
+_STAGGER_MIN_BYTES = 1 << 20   # only blocks of at least 1 MiB (fields) are staggered
+_STAGGER_STEP = 20 << 10       # 20 KiB: 5 x 4 KiB
+_STAGGER_SLOTS = 16
+_stagger_seq = itertools.count()
 
 
 def empty_cache():
@@ -221,10 +226,20 @@ class _Allocation:
     on it is ordered before the tail of `stream`, the list it is cached under.
     """
 
-    __slots__ = ("ptr", "nbytes", "device", "stream", "bucket", "exported", "_lock", "__weakref__")
+    __slots__ = ("ptr", "base", "nbytes", "device", "stream", "bucket", "exported", "_lock", "__weakref__")
 
     def __init__(self, nbytes, device):
         self.device, self.nbytes, self.stream = device, nbytes, current_stream()
+        # Large blocks start at a staggered offset inside their allocation (a different multiple of 20 KiB for
+        # each of 16 consecutive allocations).  hipMalloc returns 2-MiB-aligned blocks, so without it the fields a
+        # kernel streams together all sit at the same offset inside their pages and -- depending on where the pages
+        # land physically -- pile onto the same HBM channels: measured on four buffer sets in one process
+        # (tools/placement_probe.py, profiles/r02_placement_probe.txt) the fused pipelines vary 3.46-3.88 ms (P3) and
+        # 5.49-5.73 ms (P5) unstaggered, 3.47-3.63 and 5.41-5.58 ms staggered by k x 20 KiB.
+        stagger = 0
+        if nbytes >= _STAGGER_MIN_BYTES:
+            stagger = (next(_stagger_seq) % _STAGGER_SLOTS) * _STAGGER_STEP
+            nbytes = nbytes + _STAGGER_SLOTS * _STAGGER_STEP
         self.bucket = _BlockCache.bucket(nbytes)
         self.exported = False  # handed to a DLPack consumer, whose streams are unknown here
         self._lock = threading.Lock()
@@ -236,7 +251,7 @@ class _Allocation:
                 _cache.drain()
                 _ffi.check(_ffi.lib().ekm_malloc(device, self.bucket, C.byref(out)))
             ptr = out.value
-        self.ptr = ptr
+        self.base, self.ptr = ptr, ptr + stagger
         _cache.note(device, self.bucket)
 
     def touch(self, stream):
@@ -247,7 +262,7 @@ class _Allocation:
 
     def free(self):
         if self.ptr:
-            ptr, self.ptr = self.ptr, None
+            ptr, self.ptr, self.base = self.base, None, None
             _cache.note(self.device, -self.bucket)
             # a block a DLPack consumer has used goes back to HIP (hipFree waits for the device): the
             # consumer's streams are not known here, so stream-ordered reuse cannot be guaranteed

@@ -51,7 +51,7 @@ def test_streaming_stays_within_a_capped_device_budget(ek, monkeypatch):
     ek.empty_cache()
     ek.memory_stats(reset_peak=True)
     base = ek.memory_stats()["live_bytes"]
-    lanes, nslices = _engine.plan_slices(64, 6 * (1 << 19) * 4, cap)
+    lanes, nslices = _engine.plan_slices(64, 6 * (1 << 19) * 4, cap, overhead=6 * _engine._BLOCK_OVERHEAD)
     assert lanes >= 2 and nslices > lanes  # more slices than lanes: blocks are recycled
     got = ek.thermo.pipeline_svp_td_rh(t, q, p)
     peak = ek.memory_stats()["peak_live_bytes"] - base
