@@ -626,11 +626,11 @@ struct TeFromEpt {
 
 template <class T, class TeExact>
 EKM_HD Regime davies_regime(T c_te, T cd, T p, const TeExact& te_exact) {
-  Regime r;
-  r.r1 = cd > T(1);
-  r.r2 = T(1) <= c_te && cd <= T(1);
-  r.r3 = T(0.4) <= c_te && c_te < T(1);
-  r.r4 = c_te < T(0.4);
+  // c_dec / cd_dec: the values the four predicates are taken from.  On a tie lane they are replaced by stand-ins
+  // that fall on the side of each threshold the double evaluation found (two float merges at the join instead of
+  // four boolean ones, which cost ~8 VALU instructions per point on the fast path).
+  T c_dec = c_te, cd_dec = cd;
+#ifndef EKM_NO_TIE
   if constexpr (TeExact::have && sizeof(T) == 4) {
     // one v_min3 over |c_te/D - 1|, |c_te - 1|, |c_te/0.4 - 1| and one compare (NaN compares false: no tie)
     const T d1 = cd - T(1), d2 = c_te - T(1), d3 = c_te * T(2.5) - T(1);
@@ -640,13 +640,22 @@ EKM_HD Regime davies_regime(T c_te, T cd, T p, const TeExact& te_exact) {
       const double c = m_exp2(double(float(k::lambda)) * m_log2(double(273.16f) * m_rcp(te)));
       const double D = m_rcp(double(0.1859e-5f) * double(p) + double(0.6512f));
       if (tie) {
-        r.r1 = c > D;
-        r.r2 = 1.0 <= c && c <= D;
-        r.r3 = double(0.4f) <= c && c < 1.0;
-        r.r4 = c < double(0.4f);
+        cd_dec = c > D ? T(2) : T(0.5);  // only ever compared with 1
+        T cf = T(c);                      // keep the rounded value on the side of 1 and of 0.4 that c is on
+        if (c >= 1.0 && cf < T(1)) cf = T(1);
+        if (c < 1.0 && cf >= T(1)) cf = T(0.99999994);
+        if (c >= double(0.4f) && cf < T(0.4)) cf = T(0.4);
+        if (c < double(0.4f) && cf >= T(0.4)) cf = T(0.39999998);
+        c_dec = cf;
       }
     }
   }
+#endif
+  Regime r;
+  r.r1 = cd_dec > T(1);
+  r.r2 = T(1) <= c_dec && cd_dec <= T(1);
+  r.r3 = T(0.4) <= c_dec && c_dec < T(1);
+  r.r4 = c_dec < T(0.4);
   return r;
 }
 
