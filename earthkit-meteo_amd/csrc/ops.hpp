@@ -12,10 +12,16 @@ namespace ekm {
   struct NAME {                                                              \
     static constexpr int NIN = NIN_;                                         \
     static constexpr int NOUT = NOUT_;                                       \
+    template <class T, class Tie>                                            \
+    EKM_HD static void apply_tie(const T* __restrict__ x, T* __restrict__ y, T rp, Tie& tie) { \
+      (void)rp;                                                              \
+      (void)tie;                                                             \
+      __VA_ARGS__                                                            \
+    }                                                                        \
     template <class T>                                                       \
     EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T rp) { \
-      (void)rp;                                                              \
-      __VA_ARGS__                                                            \
+      TieInline tie;                                                         \
+      apply_tie(x, y, rp, tie);                                              \
     }                                                                        \
   };
 
@@ -24,10 +30,16 @@ namespace ekm {
   struct NAME {                                                              \
     static constexpr int NIN = NIN_;                                         \
     static constexpr int NOUT = NOUT_;                                       \
+    template <class T, class Tie>                                            \
+    EKM_HD static void apply_tie(const T* __restrict__ x, T* __restrict__ y, T rp, Tie& tie) { \
+      (void)rp;                                                              \
+      (void)tie;                                                             \
+      __VA_ARGS__                                                            \
+    }                                                                        \
     template <class T>                                                       \
     EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T rp) { \
-      (void)rp;                                                              \
-      __VA_ARGS__                                                            \
+      TieInline tie;                                                         \
+      apply_tie(x, y, rp, tie);                                              \
     }                                                                        \
   };
 
@@ -36,10 +48,16 @@ namespace ekm {
   struct NAME {                                                              \
     static constexpr int NIN = NIN_;                                         \
     static constexpr int NOUT = NOUT_;                                       \
+    template <class T, class Tie>                                            \
+    EKM_HD static void apply_tie(const T* __restrict__ x, T* __restrict__ y, T rp, Tie& tie) { \
+      (void)rp;                                                              \
+      (void)tie;                                                             \
+      __VA_ARGS__                                                            \
+    }                                                                        \
     template <class T>                                                       \
     EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T rp) { \
-      (void)rp;                                                              \
-      __VA_ARGS__                                                            \
+      TieInline tie;                                                         \
+      apply_tie(x, y, rp, tie);                                              \
     }                                                                        \
   };
 
@@ -96,11 +114,11 @@ EKM_OP_T1(OpEptFromTd, METHOD, 3, 1, y[0] = (ept<METHOD, false>(x[0], x[1], x[2]
 EKM_OP_T1(OpEptFromQ, METHOD, 3, 1, y[0] = (ept<METHOD, true>(x[0], x[1], x[2]));)
 EKM_OP_T1(OpSatEpt, METHOD, 2, 1, y[0] = ept_sat<METHOD>(x[0], x[1]);)
 // thermo.py:1472-1590
-EKM_OP_T2(OpTOnMa, METHOD, TM, 2, 1, y[0] = (t_on_ma<METHOD, TM>(x[0], x[1]));)
+EKM_OP_T2(OpTOnMa, METHOD, TM, 2, 1, y[0] = (t_on_ma<METHOD, TM>(x[0], x[1], tie));)
 EKM_OP_T2(OpWetBulbFromTd, METHOD, TM, 3, 1,
-          y[0] = (t_on_ma<METHOD, TM>(ept<METHOD, false>(x[0], x[1], x[2]), x[2]));)
+          y[0] = (t_on_ma<METHOD, TM>(ept<METHOD, false>(x[0], x[1], x[2]), x[2], tie));)
 EKM_OP_T2(OpWetBulbFromQ, METHOD, TM, 3, 1,
-          y[0] = (t_on_ma<METHOD, TM>(ept<METHOD, true>(x[0], x[1], x[2]), x[2]));)
+          y[0] = (t_on_ma<METHOD, TM>(ept<METHOD, true>(x[0], x[1], x[2]), x[2], tie));)
 // The configuration BASELINE.json names (wet-bulb from q, IFS theta_e, Newton): the chain
 // thermo.py:1589-1590 with theta_e never formed -- te = theta_e*(p/p0)^kappa = t*exp(K0*q/t_lcl)
 // because the two pressure powers cancel, which drops one exp2 and the theta products.
@@ -109,7 +127,12 @@ struct OpWetBulbFromQ<EPT_IFS, T_NEWTON> {
   static constexpr int NIN = 3;
   static constexpr int NOUT = 1;
   template <class T>
-  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T) {
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T rp) {
+    TieInline tie;
+    apply_tie(x, y, rp, tie);
+  }
+  template <class T, class Tie>
+  EKM_HD static void apply_tie(const T* __restrict__ x, T* __restrict__ y, T, Tie& tie) {
     const T t = x[0], q = x[1], p = x[2];
     const T td = t_from_es(e_from_q(q, p));
     const T tl = lcl_t<LCL_DAVIES>(t, td);
@@ -118,8 +141,28 @@ struct OpWetBulbFromQ<EPT_IFS, T_NEWTON> {
     const T lte = m_log2(t * T(1.0 / 273.16)) + xe;        // log2(te/273.16) without waiting for te
     const T pp = m_exp2(T(k::kappa) * m_log2(p * T(1.0 / k::p0)));
     const TeFromTQP<T> exact{t, q, p};
-    y[0] = t_on_ma_newton_ifs_core(te, te, lte, p, pp, T(0.1859e-5) * p + T(0.6512), exact);
+    y[0] = t_on_ma_newton_ifs_core(te, te, lte, p, pp, T(0.1859e-5) * p + T(0.6512), exact, tie);
   }
+};
+
+// ---- ops whose result depends on a Davies-Jones regime decision (thermo_math.hpp::davies_regime) ----------
+// For these the fp32 map kernels run the points with TieFlag (branch-free) and re-run, with TieExact, the points
+// of the rare lanes that recorded a tie.
+template <class Op>
+struct OpUsesTie {
+  static constexpr bool value = false;
+};
+template <int M>
+struct OpUsesTie<OpTOnMa<M, T_NEWTON>> {
+  static constexpr bool value = true;
+};
+template <int M>
+struct OpUsesTie<OpWetBulbFromTd<M, T_NEWTON>> {
+  static constexpr bool value = true;
+};
+template <int M>
+struct OpUsesTie<OpWetBulbFromQ<M, T_NEWTON>> {
+  static constexpr bool value = true;
 };
 
 // ---- ops that keep a per-workgroup table in LDS -------------------------------------------------------
@@ -167,13 +210,13 @@ struct OpTable<OpWetBulbFromQ<EPT_IFS, T_BISECT>> : BisectIfsTable {
 };
 
 // thermo.py:1593-1675: "direct" closed form, else the moist adiabat followed to p0
-template <int METHOD, int TM, class T>
-EKM_HD T wbpt_from_ept(T e) {
+template <int METHOD, int TM, class T, class Tie>
+EKM_HD T wbpt_from_ept(T e, Tie& tie) {
   if (TM == T_DIRECT) return wbpt_direct(e);
-  return t_on_ma<METHOD, TM == T_DIRECT ? T_NEWTON : TM>(e, T(k::p0));
+  return t_on_ma<METHOD, TM == T_DIRECT ? T_NEWTON : TM>(e, T(k::p0), tie);
 }
-EKM_OP_T2(OpWbptFromTd, METHOD, TM, 3, 1, y[0] = wbpt_from_ept<METHOD, TM>(ept<METHOD, false>(x[0], x[1], x[2]));)
-EKM_OP_T2(OpWbptFromQ, METHOD, TM, 3, 1, y[0] = wbpt_from_ept<METHOD, TM>(ept<METHOD, true>(x[0], x[1], x[2]));)
+EKM_OP_T2(OpWbptFromTd, METHOD, TM, 3, 1, y[0] = wbpt_from_ept<METHOD, TM>(ept<METHOD, false>(x[0], x[1], x[2]), tie);)
+EKM_OP_T2(OpWbptFromQ, METHOD, TM, 3, 1, y[0] = wbpt_from_ept<METHOD, TM>(ept<METHOD, true>(x[0], x[1], x[2]), tie);)
 template <>
 struct OpTable<OpWbptFromTd<EPT_IFS, T_BISECT>> : BisectIfsTable {
   template <class T>
@@ -187,6 +230,14 @@ struct OpTable<OpWbptFromQ<EPT_IFS, T_BISECT>> : BisectIfsTable {
   EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
     y[0] = t_on_ma_bisect_ifs_tab(ept<EPT_IFS, true>(x[0], x[1], x[2]), T(k::p0), tab);
   }
+};
+template <int M>
+struct OpUsesTie<OpWbptFromTd<M, T_NEWTON>> {
+  static constexpr bool value = true;
+};
+template <int M>
+struct OpUsesTie<OpWbptFromQ<M, T_NEWTON>> {
+  static constexpr bool value = true;
 };
 // thermo.py:1678-1707
 EKM_OP(OpGasConstant, 1, 1, y[0] = T(k::Rd) + T(k::Rv - k::Rd) * x[0];)
@@ -207,7 +258,12 @@ struct OpPipelineFull {
   static constexpr int NIN = 3;
   static constexpr int NOUT = 6;
   template <class T>
-  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T) {
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T rp) {
+    TieInline tie;
+    apply_tie(x, y, rp, tie);
+  }
+  template <class T, class Tie>
+  EKM_HD static void apply_tie(const T* __restrict__ x, T* __restrict__ y, T, Tie& tie) {
     const T t = x[0], q = x[1], p = x[2];
     const PTerms<T> P = pterms(p);
     const T th = t * P.thf;                           // thermo.py:829
@@ -228,9 +284,14 @@ struct OpPipelineFull {
 #else
     // thermo.py:1081-1159; te = theta_e*(p/p0)^kappa = t*exp(K0*q/t_lcl): the pressure powers cancel
     const TeFromTQP<T> exact{t, q, p};
-    y[5] = t_on_ma_newton_ifs_core(the, t * ex, m_log2(t * T(1.0 / 273.16)) + xe, p, P.pp, P.dinv, exact);
+    y[5] = t_on_ma_newton_ifs_core(the, t * ex, m_log2(t * T(1.0 / 273.16)) + xe, p, P.pp, P.dinv, exact, tie);
 #endif
   }
+};
+
+template <>
+struct OpUsesTie<OpPipelineFull> {
+  static constexpr bool value = true;
 };
 
 }  // namespace ekm

@@ -611,6 +611,7 @@ constexpr double kTieBand = 4e-6;  // > 3x the worst fp32 error of the fast c_te
 
 struct TeNone {  // no exact te available (fp64 kernels never need one)
   static constexpr bool have = false;
+  static constexpr int kind = 0;
   EKM_HD double operator()() const { return 0.0; }
 };
 
@@ -618,39 +619,97 @@ struct TeNone {  // no exact te available (fp64 kernels never need one)
 template <class T>
 struct TeFromEpt {
   static constexpr bool have = true;
+  static constexpr int kind = 1;
   T e, p;
   EKM_HD double operator()() const {
     return double(e) * m_exp2(double(float(k::kappa)) * m_log2(double(p) * (1.0 / k::p0)));  // p0 = 1e5 is exact in fp32
   }
 };
 
-template <class T, class TeExact>
-EKM_HD Regime davies_regime(T c_te, T cd, T p, const TeExact& te_exact) {
+// How a tie is handled is a policy of the caller:
+//   TieInline  decide in double on the spot (host twin; a wave-uniform branch inside the per-point body);
+//   TieFlag    the gfx950 kernels' first pass: decide in fp32, only RECORD that this lane met a tie -- the body stays
+//              branch-free, so the compiler can interleave the four points of a lane (with the branch inside, the
+//              wet-bulb kernel lost 4-8 %: profiles/r02_sweep_tie.txt);
+//   TieExact   the kernels' second pass, run after the four points for the (rare) lanes that recorded a tie
+//              (map_kernel.hpp::apply_points): the same arithmetic with the decision taken in double.
+// The double-precision decision itself: stand-ins for c_te/D ("cd", only ever compared with 1) and for c_te ("c",
+// compared with 1 and 0.4) on the side of each threshold that the double evaluation found.  On the device it is a
+// NOINLINE function: inlined, its fp64 code and 64-bit constants cost the fast path 20-30 VGPRs and pushed the
+// kernel to the SGPR limit (spills through v_writelane), although it runs on ~1e-5 of the points.
+struct TieDecision {
+  float cd, c;
+};
+
+EKM_HD TieDecision tie_decision_from_te(double te, double p) {
+  const double c = m_exp2(double(float(k::lambda)) * m_log2(double(273.16f) * m_rcp(te)));
+  const double D = m_rcp(double(0.1859e-5f) * p + double(0.6512f));
+  TieDecision d;
+  d.cd = c > D ? 2.0f : 0.5f;
+  float cf = float(c);  // keep the rounded value on the side of 1 and of 0.4 that c is on
+  if (c >= 1.0 && cf < 1.0f) cf = 1.0f;
+  if (c < 1.0 && cf >= 1.0f) cf = 0.99999994f;
+  if (c >= double(0.4f) && cf < 0.4f) cf = 0.4f;
+  if (c < double(0.4f) && cf >= 0.4f) cf = 0.39999998f;
+  d.c = cf;
+  return d;
+}
+
+struct TieInline {
+  static constexpr int mode = 0;
+};
+struct TieFlag {
+  static constexpr int mode = 1;
+  bool hit = false;
+};
+struct TieExact {
+  static constexpr int mode = 2;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EKM_TIE_NOINLINE __device__ __attribute__((noinline))
+#else
+#define EKM_TIE_NOINLINE inline
+#endif
+EKM_TIE_NOINLINE TieDecision tie_decide_ept(float e, float p);           // te = ept*(p/p0)^kappa
+EKM_TIE_NOINLINE TieDecision tie_decide_tqp(float t, float q, float p);  // te = t*exp(K0*q/t_lcl(t, td(q, p)))
+
+template <class TeExact, class T>
+EKM_HD TieDecision tie_decide(const TeExact& x, T p) {
+  if constexpr (TeExact::kind == 1)
+    return tie_decide_ept(float(x.e), float(x.p));
+  else if constexpr (TeExact::kind == 2)
+    return tie_decide_tqp(float(x.t), float(x.q), float(x.p));
+  else
+    return tie_decision_from_te(x(), double(p));
+}
+
+template <class T, class TeExact, class Tie>
+EKM_HD Regime davies_regime(T c_te, T cd, T p, const TeExact& te_exact, Tie& tie) {
   // c_dec / cd_dec: the values the four predicates are taken from.  On a tie lane they are replaced by stand-ins
-  // that fall on the side of each threshold the double evaluation found (two float merges at the join instead of
-  // four boolean ones, which cost ~8 VALU instructions per point on the fast path).
+  // that fall on the side of each threshold the double evaluation found.
   T c_dec = c_te, cd_dec = cd;
 #ifndef EKM_NO_TIE
   if constexpr (TeExact::have && sizeof(T) == 4) {
     // one v_min3 over |c_te/D - 1|, |c_te - 1|, |c_te/0.4 - 1| and one compare (NaN compares false: no tie)
     const T d1 = cd - T(1), d2 = c_te - T(1), d3 = c_te * T(2.5) - T(1);
-    const bool tie = m_min3abs(d1, d2, d3) < T(kTieBand);
-    if (EKM_ANY(tie)) {
-      const double te = te_exact();
-      const double c = m_exp2(double(float(k::lambda)) * m_log2(double(273.16f) * m_rcp(te)));
-      const double D = m_rcp(double(0.1859e-5f) * double(p) + double(0.6512f));
-      if (tie) {
-        cd_dec = c > D ? T(2) : T(0.5);  // only ever compared with 1
-        T cf = T(c);                      // keep the rounded value on the side of 1 and of 0.4 that c is on
-        if (c >= 1.0 && cf < T(1)) cf = T(1);
-        if (c < 1.0 && cf >= T(1)) cf = T(0.99999994);
-        if (c >= double(0.4f) && cf < T(0.4)) cf = T(0.4);
-        if (c < double(0.4f) && cf >= T(0.4)) cf = T(0.39999998);
-        c_dec = cf;
+    const bool is_tie = m_min3abs(d1, d2, d3) < T(kTieBand);
+    if constexpr (Tie::mode == 1) {
+      tie.hit = tie.hit || is_tie;
+    } else {
+      bool enter = is_tie;
+      if constexpr (Tie::mode == 0) enter = EKM_ANY(is_tie);
+      if (enter) {
+        if (is_tie) {
+          const TieDecision dec = tie_decide(te_exact, p);
+          cd_dec = T(dec.cd);
+          c_dec = T(dec.c);
+        }
       }
     }
   }
 #endif
+  (void)tie;
   Regime r;
   r.r1 = cd_dec > T(1);
   r.r2 = T(1) <= c_dec && cd_dec <= T(1);
@@ -686,12 +745,12 @@ EKM_HD PTerms<T> pterms(T p) {
 // the negated exponent, the Newton residual 1 - c_te/f from ONE exp2 (the exponents of c_te, c_tw and
 // exp(G) add), reciprocals shared between qs and its slope, and regime / phase work skipped by whole
 // waves that do not need it.  `lte` = log2(te/273.16); `te` itself is only needed by the regime-1 guess.
-template <class T, class TeExact>
-EKM_HD T t_on_ma_newton_ifs_core(T e, T te, T lte, T p, T pp, T dinv, const TeExact& te_exact) {
+template <class T, class TeExact, class Tie>
+EKM_HD T t_on_ma_newton_ifs_core(T e, T te, T lte, T p, T pp, T dinv, const TeExact& te_exact, Tie& tie) {
   const T lam = T(k::lambda);
   const T c_te = m_exp2(-lam * lte);  // (t0/te)^lambda
   const T cd = c_te * dinv;           // c_te / D
-  const Regime R = davies_regime(c_te, cd, p, te_exact);
+  const Regime R = davies_regime(c_te, cd, p, te_exact, tie);
 
   // initial guess in deg C; later regimes overwrite earlier ones (thermo.py:1114-1128)
   T tw = e;
@@ -740,11 +799,11 @@ EKM_HD T t_on_ma_newton_ifs_core(T e, T te, T lte, T p, T pp, T dinv, const TeEx
 }
 
 // theta_e given (temperature_on_moist_adiabat, wet-bulb from dewpoint, theta_w by Newton)
-template <class T>
-EKM_HD T t_on_ma_newton_ifs(T e, const PTerms<T>& P) {
+template <class T, class Tie>
+EKM_HD T t_on_ma_newton_ifs(T e, const PTerms<T>& P, Tie& tie) {
   const T te = e * P.pp;  // thermo.py:1110
   const TeFromEpt<T> exact{e, P.p};
-  return t_on_ma_newton_ifs_core(e, te, m_log2(te * T(1.0 / 273.16)), P.p, P.pp, P.dinv, exact);
+  return t_on_ma_newton_ifs_core(e, te, m_log2(te * T(1.0 / 273.16)), P.p, P.pp, P.dinv, exact, tie);
 }
 
 // te = theta_e*(p/p0)^kappa for the IFS theta_e from specific humidity (thermo.py:1169-1175 with td from
@@ -754,6 +813,7 @@ EKM_HD T t_on_ma_newton_ifs(T e, const PTerms<T>& P) {
 template <class T>
 struct TeFromTQP {
   static constexpr bool have = true;
+  static constexpr int kind = 2;
   T t, q, p;
   EKM_HD double operator()() const {
     const double td_ = double(t), qd = double(q), pd = double(p);
@@ -766,10 +826,19 @@ struct TeFromTQP {
   }
 };
 
+EKM_TIE_NOINLINE TieDecision tie_decide_ept(float e, float p) {
+  const TeFromEpt<float> x{e, p};
+  return tie_decision_from_te(x(), double(p));
+}
+EKM_TIE_NOINLINE TieDecision tie_decide_tqp(float t, float q, float p) {
+  const TeFromTQP<float> x{t, q, p};
+  return tie_decision_from_te(x(), double(p));
+}
+
 // Davies-Jones (2008): regime initial guess + exactly one Newton step
 // (max_iter = 1, thermo.py:1104), tw <= 0 -> NaN (thermo.py:1081-1159).
-template <int METHOD, class T>
-EKM_HD T t_on_ma_newton(T e, T p) {
+template <int METHOD, class T, class Tie>
+EKM_HD T t_on_ma_newton(T e, T p, Tie& tie) {
   const T t0 = T(273.16);
   const T A = T(2675);
   const T lam = T(k::lambda);
@@ -789,7 +858,7 @@ EKM_HD T t_on_ma_newton(T e, T p) {
     const T k1 = poly2(pp, -53.737, 137.81, -38.5);
     const T k2 = poly2(pp, -0.384, 56.831, -4.392);
     const TeFromEpt<T> exact{e, p};
-    const Regime R = davies_regime(c_te, c_te * (T(0.1859e-5) * p + T(0.6512)), p, exact);
+    const Regime R = davies_regime(c_te, c_te * (T(0.1859e-5) * p + T(0.6512)), p, exact, tie);
     if (R.r1) tw = g1;
     if (R.r2) tw = k1 - k2 * c_te;
     if (R.r3) tw = (k1 - T(1.21)) - (k2 - T(1.21)) * c_te;
@@ -832,11 +901,11 @@ EKM_HD T t_on_ma_newton(T e, T p) {
   return tw;
 }
 
-template <int METHOD, int TM, class T>
-EKM_HD T t_on_ma(T e, T p) {  // thermo.py:1472-1509
+template <int METHOD, int TM, class T, class Tie>
+EKM_HD T t_on_ma(T e, T p, Tie& tie) {  // thermo.py:1472-1509
   if (TM == T_BISECT) return t_on_ma_bisect<METHOD>(e, p);
-  if (METHOD == EPT_IFS) return t_on_ma_newton_ifs(e, pterms(p));
-  return t_on_ma_newton<METHOD>(e, p);
+  if (METHOD == EPT_IFS) return t_on_ma_newton_ifs(e, pterms(p), tie);
+  return t_on_ma_newton<METHOD>(e, p, tie);
 }
 
 }  // namespace ekm
