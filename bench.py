@@ -381,10 +381,10 @@ def main():
     if not args.dry_run:
         _ffi.check(lib.ekm_event_record(dev, evs[-1], None))
     sync()
-    dist.barrier()
+    elapsed = time.perf_counter() - t0  # this rank's K steps, from the common start to its own device sync
+    dist.barrier()                      # the closing bracket: nobody reports before everybody has finished
     sync()
-    elapsed = time.perf_counter() - t0
-    elapsed = dist.reduce(elapsed, "max")
+    elapsed = dist.reduce(elapsed, "max")  # the job took as long as its slowest rank
 
     ndev_seen, dev_used, my_ms = -1, -1, float("nan")
     if not args.dry_run:

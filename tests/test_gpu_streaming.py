@@ -145,3 +145,31 @@ def test_dlpack_with_torch_as_foreign_producer_and_consumer(ek):
         pytest.skip(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "torch unavailable")
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "DLPACK_TORCH_OK" in r.stdout
+
+
+def test_bench_two_ranks_strong_scaling_on_one_device(ek):
+    """bench.py under torch.distributed.run with 2 ranks sharing this GPU: the N > 1 path on real hardware --
+    one field split by grid point (config 5's sharding), gloo barrier only, parity of rank 0's shard, the per-rank
+    report.  (Two ranks on one device share its bandwidth: the value is not a scaling measurement.)"""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--levels", "16", "--pmode", "level"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["parity"]["ok"] and d["parity"]["nan_mismatch"] == 0
+    ranks = d["config"]["per_rank"]
+    assert [x["points"] for x in ranks] == [8 * 1800 * 3600] * 2 and all(x["kernel_ms"] > 0 for x in ranks)
+    assert all(x["hip_device_count"] >= 1 for x in ranks)
