@@ -598,8 +598,8 @@ EKM_HD T t_on_ma_bisect(T e, T p) {
 // of a threshold differ (by ~2 K at 10 hPa), so a point whose c_te is within rounding noise of a threshold
 // must take the reference's decision, not the one our differently rounded fp32 c_te happens to give.  The
 // fp32 kernels therefore re-derive the four predicates in DOUBLE on the rare lanes whose fast c_te lies
-// within kTieBand of a threshold (a wave-uniform branch: ~0.1 % of the waves of the benchmark field enter
-// it): te is recomputed from the op's own inputs by `te_exact()`, then c_te and D in the reference's operator
+// within kTieBand of a threshold (~1.3e-5 of the points of the benchmark field; ~0.3 % of its waves hold
+// one): te is recomputed from the op's own inputs by `te_exact()`, then c_te and D in the reference's operator
 // order with the reference's fp32-rounded constants -- power(t0/te, lambda), 1/(0.1859e-5*p + 0.6512),
 // c_te > D, 1 <= c_te <= D, 0.4 <= c_te < 1, c_te < 0.4 -- i.e. what the reference's fp32 sequence computes
 // up to its own rounding noise.  The guess FORMULAS stay in fp32 (they are continuous in c_te).
@@ -626,13 +626,6 @@ struct TeFromEpt {
   }
 };
 
-// How a tie is handled is a policy of the caller:
-//   TieInline  decide in double on the spot (host twin; a wave-uniform branch inside the per-point body);
-//   TieFlag    the gfx950 kernels' first pass: decide in fp32, only RECORD that this lane met a tie -- the body stays
-//              branch-free, so the compiler can interleave the four points of a lane (with the branch inside, the
-//              wet-bulb kernel lost 4-8 %: profiles/r02_sweep_tie.txt);
-//   TieExact   the kernels' second pass, run after the four points for the (rare) lanes that recorded a tie
-//              (map_kernel.hpp::apply_points): the same arithmetic with the decision taken in double.
 // The double-precision decision itself: stand-ins for c_te/D ("cd", only ever compared with 1) and for c_te ("c",
 // compared with 1 and 0.4) on the side of each threshold that the double evaluation found.  On the device it is a
 // NOINLINE function: inlined, its fp64 code and 64-bit constants cost the fast path 20-30 VGPRs and pushed the
@@ -655,6 +648,13 @@ EKM_HD TieDecision tie_decision_from_te(double te, double p) {
   return d;
 }
 
+// How a tie is handled is a policy of the caller:
+//   TieInline  decide in double on the spot (host twin; a wave-uniform branch inside the per-point body);
+//   TieFlag    the gfx950 kernels' first pass: decide in fp32, only RECORD that this lane met a tie -- the body stays
+//              branch-free, so the compiler can interleave the four points of a lane (with the branch inside, the
+//              wet-bulb kernel lost 4-8 %: profiles/r02_sweep_tie.txt);
+//   TieExact   the kernels' second pass, run after the four points for the (rare) lanes that recorded a tie
+//              (map_kernel.hpp::apply_points): the same arithmetic with the decision taken in double.
 struct TieInline {
   static constexpr int mode = 0;
 };
