@@ -270,20 +270,30 @@ int ekm_host_prefault(void* ptr, size_t bytes, int nthreads) {
   // Make the pages of a freshly allocated host buffer exist (writable) before a device-to-host copy lands
   // in them: first-touch faults otherwise throttle the copy 56 -> 16 GB/s.  NON-DESTRUCTIVE: the contents
   // of the buffer are never changed, so it is safe even while data is arriving in it.
-  // madvise(MADV_POPULATE_WRITE) (Linux >= 5.14) where available; else an atomic `or 0` per page, which
-  // takes the write fault and stores back the value it read in one locked operation.
+  // madvise(MADV_POPULATE_WRITE) (Linux >= 5.14) where available (94 GB/s with 4 threads on the GPU box's host);
+  // else a compare-and-swap of one byte per page with itself.
   if (!ptr || bytes == 0) return EKM_OK;
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 16) nthreads = 16;
   char* base = static_cast<char*>(ptr);
   auto work = [base, bytes](size_t lo, size_t hi) {
 #if defined(MADV_POPULATE_WRITE)
-    const uintptr_t a0 = (reinterpret_cast<uintptr_t>(base) + lo) & ~uintptr_t(4095);
-    const uintptr_t a1 = (reinterpret_cast<uintptr_t>(base) + hi + 4095) & ~uintptr_t(4095);
-    if (madvise(reinterpret_cast<void*>(a0), a1 - a0, MADV_POPULATE_WRITE) == 0) return;
+    static const bool use_madvise = env_int("EKM_PREFAULT_MADVISE", 1, 0, 1) != 0;
+    if (use_madvise) {
+      const uintptr_t a0 = (reinterpret_cast<uintptr_t>(base) + lo) & ~uintptr_t(4095);
+      const uintptr_t a1 = (reinterpret_cast<uintptr_t>(base) + hi + 4095) & ~uintptr_t(4095);
+      if (madvise(reinterpret_cast<void*>(a0), a1 - a0, MADV_POPULATE_WRITE) == 0) return;
+    }
 #endif
-    for (size_t off = lo; off < hi; off += 4096) __atomic_fetch_or(base + off, 0, __ATOMIC_RELAXED);
-    if (hi == bytes) __atomic_fetch_or(base + bytes - 1, 0, __ATOMIC_RELAXED);
+    // compare-and-swap of a byte with itself: always a locked write of the value just read (an atomic `or 0` is
+    // folded into a plain load by the compiler and would not take the write fault)
+    auto touch = [](char* p) {
+      char v = __atomic_load_n(p, __ATOMIC_RELAXED);
+      while (!__atomic_compare_exchange_n(p, &v, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+      }
+    };
+    for (size_t off = lo; off < hi; off += 4096) touch(base + off);
+    if (hi == bytes) touch(base + bytes - 1);
   };
   const size_t pages = (bytes + 4095) / 4096, per = (pages + nthreads - 1) / nthreads * 4096;
   std::vector<std::thread> pool;

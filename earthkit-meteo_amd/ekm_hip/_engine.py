@@ -235,11 +235,13 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
 
     * several GPUs (`multi_gpu()`): one contiguous block of rows per GPU (~17 whole levels each for
       [137, lat, lon] fields on 8 GPUs), no exchange of any kind;
-    * per GPU: `lanes` host threads, each with its own stream, take slices from a queue -- the upload of one
-      slice overlaps the kernel and the download of others (PCIe is full duplex); the device blocks of a
-      finished slice go back to the block cache of that lane's stream and are reused by its next slice, so the
+    * per GPU: an uploader thread (slice k: upload its operands, launch, hand over) and a downloader thread (slice
+      k: download its results, free its device blocks) with `lanes` slices resident between them, each on the
+      stream (device, k mod lanes): exactly one upload and one download are in flight at a time -- PCIe is full
+      duplex, but concurrent pageable uploads collapse -- and the kernels run under both; a collected slice's
+      device blocks go back to the block cache of its stream and are taken again `lanes` slices later, so the
       device working set is lanes x slice, chosen to fit `stream_budget_bytes` (fields larger than HBM stream
-      through; with a tight budget this degrades to two slices in flight, i.e. double buffering)."""
+      through; with a tight budget this degrades to two resident slices, i.e. double buffering)."""
     import queue
 
     from .device import set_device, set_stream
@@ -268,32 +270,75 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
         plans.append(pl)
     outs = [np.empty(shape, out_dtype) for _ in range(nout)]
     errors = []
+    slices, ready = [], {}  # per device: its slices in order; per slice: "its result pages exist" event
+    for (lo, hi), (lanes, nslices) in zip(blocks, plans):
+        mine = [(lo + a, lo + b) for a, b in leading_axis_bounds(hi - lo, nslices) if b > a]
+        slices.append(mine)
+        for sl in mine:
+            ready[sl] = threading.Event()
 
-    def lane(dev, slot, todo):
+    def toucher():
+        # fault in the result pages slice by slice, in the order the downloads will need them, all GPUs interleaved
+        try:
+            lib = _ffi.lib()
+            for k in range(max(len(m) for m in slices)):
+                for mine in slices:
+                    if k < len(mine):
+                        lo, hi = mine[k]
+                        if outs[0][lo:hi].nbytes >= _PRETOUCH_BYTES // 8:
+                            for o in outs:
+                                lib.ekm_host_prefault(o[lo:hi].ctypes.data, o[lo:hi].nbytes, 4)
+                        ready[mine[k]].set()
+        finally:
+            for ev in ready.values():
+                ev.set()
+
+    def uploader(dev, mine, depth, slots, handoff):
+        # ONE host-to-device copy in flight per GPU: concurrent pageable uploads collapse (207 MB in 1 / 2 / 4 / 8
+        # threads: 48 / 53 / 19 / 16 GB/s), while an upload and a download run together at full rate (PCIe duplex)
         try:
             set_device(dev)
-            set_stream(_lane_stream(dev, slot))
-            while not errors:
-                try:
-                    lo, hi = todo.get_nowait()
-                except queue.Empty:
-                    return
+            for k, (lo, hi) in enumerate(mine):
+                slots.acquire()  # at most `depth` slices resident on the device
+                if errors:
+                    break
+                set_stream(_lane_stream(dev, k % depth))
                 # operands that span the leading axis get the matching slice; everything else is passed as
                 # the caller gave it (a Python scalar must stay a weak scalar for the dtype promotion)
                 part = [h[lo:hi] if sp else a for h, a, sp in zip(host, args, spans)]
-                dest = [o[lo:hi] for o in outs]
-                _run_single(name, part, ints, eps, dtype, host_out=dest,
-                            toucher=_pretouch(dest) if dest[0].nbytes >= _PRETOUCH_BYTES else None)
+                handoff.put(((lo, hi), _submit(name, part, ints, eps, dtype, host_out=[o[lo:hi] for o in outs])))
         except BaseException as exc:  # surfaced in the calling thread
             errors.append(exc)
+        finally:
+            handoff.put(None)
 
-    threads = []
-    for dev, (lo, hi), (lanes, nslices) in zip(devs, blocks, plans):
-        todo = queue.Queue()
-        for a, b in leading_axis_bounds(hi - lo, nslices):
-            if b > a:
-                todo.put((lo + a, lo + b))
-        threads += [threading.Thread(target=lane, args=(dev, slot, todo)) for slot in range(lanes)]
+    def downloader(dev, slots, handoff):
+        # ... and ONE device-to-host copy; a collected slice's device blocks go back to the block cache of its
+        # stream and are taken again when the uploader comes round to that stream
+        try:
+            set_device(dev)
+            while True:
+                item = handoff.get()
+                if item is None:
+                    return
+                sl, pend = item
+                try:
+                    if not errors:
+                        ready[sl].wait()
+                        set_stream(pend.stream)
+                        _collect(pend)
+                finally:
+                    slots.release()
+        except BaseException as exc:
+            errors.append(exc)
+            while handoff.get() is not None:  # drain, so that the uploader is never left blocked
+                slots.release()
+
+    threads = [threading.Thread(target=toucher)]
+    for dev, mine, (depth, _n) in zip(devs, slices, plans):
+        slots, handoff = threading.Semaphore(depth), queue.Queue()
+        threads.append(threading.Thread(target=uploader, args=(dev, mine, depth, slots, handoff)))
+        threads.append(threading.Thread(target=downloader, args=(dev, slots, handoff)))
     for th in threads:
         th.start()
     for th in threads:
@@ -303,9 +348,21 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
     return tuple(outs)
 
 
+class _Pending:
+    """One submitted launch: device results (and the temporaries its operands live in) not yet collected."""
+
+    __slots__ = ("plan", "results", "temps", "host_out", "internal_out", "toucher", "stream")
+
+
 def _run_single(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=None):
     """One launch.  `host_out` (caller-owned NumPy destinations, e.g. slices of a result array) receives the
     outputs directly; `toucher` is a thread prefaulting them, joined before anything is downloaded."""
+    return _collect(_submit(name, args, ints, eps, dtype, host_out, toucher))
+
+
+def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=None):
+    """Upload what lives on the host, launch, return without waiting for the kernel (the uploads themselves are
+    synchronous copies on the current stream)."""
     ins, outs, int_names, has_eps = OPS[name]
     assert len(args) == len(ins) and len(ints) == len(int_names)
     plan = _Plan(args, dtype)
@@ -362,7 +419,17 @@ def _run_single(name, args, ints=(), eps=None, dtype=None, host_out=None, touche
         cargs.append(float(eps))
     cargs += [r.ptr for r in results] + [plan.n]
     _ffi.check(fn(*cargs))
+    pend = _Pending()
+    pend.plan, pend.results, pend.temps, pend.host_out = plan, results, temps, host_out
+    pend.internal_out, pend.toucher, pend.stream = internal_out, toucher, stream
+    return pend
 
+
+def _collect(pend):
+    """Results of a submitted launch: DeviceArrays as they are, NumPy results downloaded on the CURRENT stream
+    (which must be the stream the launch was submitted on)."""
+    plan, results, temps, host_out = pend.plan, pend.results, pend.temps, pend.host_out
+    internal_out, toucher = pend.internal_out, pend.toucher
     if plan.on_device:
         # temporaries are freed by HIP in stream order after the kernel has run
         for t in temps:
