@@ -67,9 +67,6 @@ struct MapArgs {
   const T* aux1;                 //                                 B half-level table
 };
 
-#ifndef EKM_SCHED_SPLIT
-#define EKM_SCHED_SPLIT 0  // (unused since round 2: the point bodies are generated by apply_points)
-#endif
 #ifndef EKM_NT_LOAD
 #define EKM_NT_LOAD 1
 #endif
@@ -372,6 +369,8 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_levels(const L
     const unsigned col = (unsigned)col64;
 
     T ph0[V], s[V];  // PM_HYBRID: lower half-level pressure carried up the column, surface pressure
+    T a0 = T(0), b0 = T(1);
+    bool sp_finite = true;  // wave-uniform: every lane's surface pressure is finite
     if (PMODE == PM_HYBRID) {
       const T* sp = a.in[PI];
       if (ALIGNED && col + V <= a.inner) {
@@ -383,9 +382,15 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_levels(const L
         for (int j = 0; j < V; ++j) s[j] = (col + j < a.inner) ? sp[col + j] : T(1);
       }
       const unsigned kk = k0 <= a.last ? k0 : a.last;
-      const T a0 = a.A[kk], b0 = a.B[kk];
+      a0 = a.A[kk];
+      b0 = a.B[kk];
+      bool fin = true;
 #pragma unroll
-      for (int j = 0; j < V; ++j) ph0[j] = a0 + b0 * s[j];
+      for (int j = 0; j < V; ++j) {
+        ph0[j] = a0 + b0 * s[j];
+        fin = fin && (s[j] - s[j] == T(0));
+      }
+      sp_finite = __builtin_amdgcn_ballot_w64(!fin) == 0ull;
     }
 
     for (unsigned l = 0; l < a.lev_per_wg; ++l) {
@@ -398,53 +403,71 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_levels(const L
       if (col >= rowlen) break;
       const unsigned long long e0 = row + col;
 
-      T pv[V];
-      if (PMODE == PM_HYBRID) {
-        const T a1 = a.A[kk + 1], b1 = a.B[kk + 1];
+      // one level of this lane's chunk, pressure given per point by `pressure(j)`
+      auto run_level = [&](auto pressure) {
+        if (ALIGNED && col + V <= rowlen) {
+          Vec xin[NIN > 1 ? NIN - 1 : 1], yout[NOUT];
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-          const T ph1 = a1 + b1 * s[j];
-          pv[j] = ph0[j] + T(0.5) * (ph1 - ph0[j]);
-          ph0[j] = ph1;
-        }
-      } else {
-        const T pl = a.in[PI][kk];
+          for (int f = 0; f < PI; ++f) xin[f] = ld_stream<T>(a.in[f] + e0);
+          T x[V][NIN], y[V][NOUT];
 #pragma unroll
-        for (int j = 0; j < V; ++j) pv[j] = pl;
-      }
-
-      if (ALIGNED && col + V <= rowlen) {
-        Vec xin[NIN > 1 ? NIN - 1 : 1], yout[NOUT];
+          for (int j = 0; j < V; ++j) {
 #pragma unroll
-        for (int f = 0; f < PI; ++f) xin[f] = ld_stream<T>(a.in[f] + e0);
-        T x[V][NIN], y[V][NOUT];
+            for (int f = 0; f < PI; ++f) x[j][f] = xin[f][j];
+            x[j][PI] = pressure(j);
+          }
+          apply_points<Op, T, V>(x, y, a.rp, op_tab);
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
+          for (int j = 0; j < V; ++j) {
 #pragma unroll
-          for (int f = 0; f < PI; ++f) x[j][f] = xin[f][j];
-          x[j][PI] = pv[j];
-        }
-        apply_points<Op, T, V>(x, y, a.rp, op_tab);
+            for (int o = 0; o < NOUT; ++o) yout[o][j] = y[j][o];
+          }
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
+          for (int o = 0; o < NOUT; ++o) st_stream<T>(a.out[o] + e0, yout[o]);
+        } else {  // unaligned rows / ragged end of a row: element by element
 #pragma unroll
-          for (int o = 0; o < NOUT; ++o) yout[o][j] = y[j][o];
-        }
+          for (int j = 0; j < V; ++j) {
+            if (col + j < rowlen) {
+              T x[NIN], y[NOUT];
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) st_stream<T>(a.out[o] + e0, yout[o]);
-      } else {  // unaligned rows / ragged end of a row: element by element
+              for (int f = 0; f < PI; ++f) x[f] = a.in[f][e0 + j];
+              x[PI] = pressure(j);
+              op_apply<Op, T>(x, y, a.rp, op_tab);
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-          if (col + j < rowlen) {
-            T x[NIN], y[NOUT];
-#pragma unroll
-            for (int f = 0; f < PI; ++f) x[f] = a.in[f][e0 + j];
-            x[PI] = pv[j];
-            op_apply<Op, T>(x, y, a.rp, op_tab);
-#pragma unroll
-            for (int o = 0; o < NOUT; ++o) a.out[o][e0 + j] = y[o];
+              for (int o = 0; o < NOUT; ++o) a.out[o][e0 + j] = y[o];
+            }
           }
         }
+      };
+
+      if (PMODE == PM_HYBRID) {
+        const T a1 = a.A[kk + 1], b1 = a.B[kk + 1];
+        // Only for the VALU-bound single-output ops (wet-bulb family: 3.74 -> 3.36 ms): the second copy of the body
+        // buys nothing for HBM-bound ops and costs the six-output pipeline occupancy and instruction cache
+        // (5.67 -> 5.9 ms), so those take the general branch on every level.
+        constexpr bool kFlatLevels = NOUT == 1 && (OpUsesTie<Op>::value || OpTable<Op>::elems > 0);
+        if (kFlatLevels && b0 == T(0) && b1 == T(0) && sp_finite) {
+          // a pure pressure level (the upper 53 of the 137 IFS levels): p does not depend on sp, so the level runs
+          // like a level-vector one -- pressure-only sub-expressions once per chunk instead of once per point
+          const T pl = a0 + T(0.5) * (a1 - a0);
+          run_level([&](int) { return pl; });
+#pragma unroll
+          for (int j = 0; j < V; ++j) ph0[j] = a1;
+        } else {
+          T pv[V];
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            const T ph1 = a1 + b1 * s[j];
+            pv[j] = ph0[j] + T(0.5) * (ph1 - ph0[j]);
+            ph0[j] = ph1;
+          }
+          run_level([&](int j) { return pv[j]; });
+        }
+        a0 = a1;
+        b0 = b1;
+      } else {
+        const T pl = a.in[PI][kk];
+        run_level([&](int) { return pl; });
       }
     }
   }
