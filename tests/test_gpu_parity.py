@@ -602,3 +602,25 @@ def test_dlpack_round_trip(ek):
     assert len(dlpack._exports) == 0                  # never consumed: released by the capsule destructor
     with pytest.raises(TypeError):
         ek.from_dlpack(object())
+
+
+@pytest.mark.parametrize("nlev,inner", [(3, 255), (3, 256), (5, 260), (7, 1023), (4, 4097), (70000, 256), (66000, 257), (1, 5000)])
+def test_level_vector_shapes_pick_the_right_kernel(ek, orc, nlev, inner):
+    """Fields + a per-level pressure vector for row lengths around every dispatch boundary of launch_map: rows shorter
+    than a workgroup (LDS-staged map_bcast), rows that are not a multiple of 16 B (unaligned map_levels), ragged tiles,
+    and more levels than gridDim.y allows (map_bcast again).  All must equal the full-field result bit for bit."""
+    rng = np.random.default_rng(nlev * 1000 + inner)
+    t = rng.uniform(200.0, 310.0, (nlev, inner)).astype(np.float32)
+    q = rng.uniform(1e-6, 0.02, (nlev, inner)).astype(np.float32)
+    pl = np.linspace(2000.0, 101000.0, nlev, dtype=np.float32)[:, None]
+    pf = np.ascontiguousarray(np.broadcast_to(pl, t.shape))
+    for func, args_lev, args_full in (("potential_temperature", (t, pl), (t, pf)),
+                                      ("pipeline_svp_td_rh", (t, q, pl), (t, q, pf)),
+                                      ("wet_bulb_temperature_from_specific_humidity", (t, q, pl), (t, q, pf))):
+        kw = {"t_method": "newton"} if func.startswith("wet_bulb") else {}
+        a = _outs(getattr(ek.thermo, func)(*args_lev, **kw))
+        b = _outs(getattr(ek.thermo, func)(*args_full, **kw))
+        for x, y in zip(a, b):
+            assert x.shape == t.shape and np.array_equal(x, y, equal_nan=True), (func, nlev, inner)
+    want = orc.potential_temperature(t, pl)
+    assert_parity(ek.thermo.potential_temperature(t, pl), want, "f32", f"theta level vector {nlev}x{inner}")
