@@ -92,3 +92,25 @@ def test_product_never_imports_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in src and "_hosttwin" not in src, fn
+
+
+def test_tuning_parameters_by_name_need_no_gpu():
+    """ekm_set_tuning / ekm_set_tuning_param are host-side state: usable (and range-checked) without a device."""
+    from ekm_hip import _ffi
+
+    lib = _ffi.lib()
+    assert lib.ekm_set_tuning_param(b"hybrid_band_kb", 4096) == 0 and lib.ekm_set_tuning_param(b"hybrid_band_kb", 8192) == 0
+    assert lib.ekm_set_tuning_param(b"geo_chunk_levels", 1 << 20) == 0 and lib.ekm_set_tuning_param(b"lev_per_wg", 0) == 0
+    assert lib.ekm_set_tuning_param(b"table_tiles", 16) == 0
+    assert lib.ekm_set_tuning_param(b"table_tiles", 0) == _ffi.EKM_ERR_ARG and b"table_tiles" in lib.ekm_last_error()
+    assert lib.ekm_set_tuning_param(b"no_such_parameter", 1) == _ffi.EKM_ERR_ARG
+    assert b"unknown parameter" in lib.ekm_last_error()
+    assert lib.ekm_set_tuning_param(None, 1) == _ffi.EKM_ERR_ARG
+    t, u = C.c_int(), C.c_int()
+    assert lib.ekm_get_tuning(C.byref(t), C.byref(u)) == 0 and t.value >= 1 and u.value in (1, 2)
+    assert lib.ekm_set_tuning(0, 3) == _ffi.EKM_ERR_ARG
+
+
+def test_wind_entry_point_cites_the_reference():
+    text = open(HEADER).read()
+    assert "ekm_w_from_omega_f32" in text and "wind/array/wind.py:192-222" in text
