@@ -28,6 +28,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--levels", type=int, default=137)
     ap.add_argument("--out", default="")
+    ap.add_argument("--pmode", default="field", choices=["field", "level", "hybrid"],
+                    help="pressure as a full field, as the 137-level vector, or formed in the kernel from sp + A/B tables")
     a = ap.parse_args()
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))
     pool = mp.get_context("fork").Pool(cores)  # before HIP is initialised in this process
@@ -39,24 +41,55 @@ def main():
     n = nlev * inner
     lib = _ffi.lib()
     t, q, p = (ekm_hip.DeviceArray.empty((n,), np.float32) for _ in range(3))
-    _ffi.check(lib.ekm_synth_fill_f32(0, None, t.ptr, q.ptr, p.ptr, 0, n, inner, nlev, 20260313))
-    outs = thermo.pipeline_full(t, q, p)
+    plev_host = sp_host = Ah = Bh = None
+    if a.pmode == "hybrid":
+        from oracle import vertical_oracle as vo
+
+        g = np.load(os.path.join(ROOT, "tests", "golden", "vertical_golden.npz"))
+        Ah, Bh = (g[f"coef.137.{k}"][137 - nlev:].astype(np.float32) for k in "AB")
+        sp_host = (101325.0 * (1.0 - 0.35 * np.random.default_rng(20260313).random(inner) ** 3)).astype(np.float32)
+        hp = ekm_hip.HybridPressure(Ah, Bh, ekm_hip.to_device(sp_host))
+        # t, q drawn around the hybrid-level pressure (materialised once for the generator, then dropped)
+        _ffi.check(lib.ekm_pressure_on_hybrid_levels_f32(0, None, ekm_hip.to_device(Ah).ptr, ekm_hip.to_device(Bh).ptr,
+                                                         hp.sp.ptr, inner, nlev, None, None, 1, float(np.log(2)), p.ptr,
+                                                         None, None, None))
+        _ffi.check(lib.ekm_synth_fill_given_p_f32(0, None, t.ptr, q.ptr, p.ptr, 0, n, 20260313))
+        ekm_hip.synchronize()
+        outs = thermo.pipeline_full(t.reshape(nlev, inner), q.reshape(nlev, inner), hp)
+    elif a.pmode == "level":
+        plev = ekm_hip.DeviceArray.empty((nlev,), np.float32)
+        _ffi.check(lib.ekm_synth_levels_f32(0, None, plev.ptr, nlev))
+        _ffi.check(lib.ekm_synth_fill_f32(0, None, t.ptr, q.ptr, None, 0, n, inner, nlev, 20260313))
+        plev_host = plev.to_host()
+        outs = thermo.pipeline_full(t.reshape(nlev, inner), q.reshape(nlev, inner), plev.reshape(nlev, 1))
+    else:
+        _ffi.check(lib.ekm_synth_fill_f32(0, None, t.ptr, q.ptr, p.ptr, 0, n, inner, nlev, 20260313))
+        outs = thermo.pipeline_full(t, q, p)
+    outs = tuple(o.ravel() for o in outs)
     ekm_hip.synchronize()
 
     from oracle import census
 
-    parts = []
+    parts, per_level = [], []
     t0 = time.time()
     chunk = inner // cores // 4 * 4
     for lev in range(nlev):
         base = lev * inner
         host = [x.flat_slice(base, base + inner).to_host() for x in (t, q, p) + tuple(outs)]
+        if a.pmode == "level":  # the oracle gets the level's pressure as the reference would: broadcast over the level
+            host[2] = np.full(inner, plev_host[lev], np.float32)
+        elif a.pmode == "hybrid":  # ... or the hybrid definition evaluated by the (pinned) vertical oracle
+            host[2] = np.ascontiguousarray(vo.pressure_on_hybrid_levels(Ah[lev:lev + 2], Bh[lev:lev + 2], sp_host)[0]
+                                           .astype(np.float32))
         jobs = []
         for lo in range(0, inner, chunk):
             hi = min(lo + chunk, inner)
             jobs.append(dict(kind="full", t=host[0][lo:hi], q=host[1][lo:hi], p=host[2][lo:hi],
                              got=[h[lo:hi] for h in host[3:]], tw_index=5))
         parts.append(census.merge(pool.map(census.job, jobs)))
+        per_level.append(dict(level=lev, p_mean=float(np.mean(host[2], dtype=np.float64)), tw_over=parts[-1][5]["over"],
+                              tw_reference_fp32_vs_fp64_over=parts[-1][5]["reference_fp32_vs_fp64_over"],
+                              tw_max_rel=parts[-1][5]["max_rel"]))
         if lev % 8 == 0:
             tw = census.merge(parts)[5]
             print(f"level {lev + 1}/{nlev}  {time.time() - t0:.0f} s  tw: beyond 1e-4 so far {tw['over']} "
@@ -64,7 +97,8 @@ def main():
     total = dict(zip(NAMES, census.merge(parts)))
     npts = n
     pool.close()
-    res = dict(points=npts, levels=nlev, tolerance=1e-4, outputs=total, excluded_points=0,
+    res = dict(points=npts, levels=nlev, p_mode=a.pmode, tolerance=1e-4, outputs=total, excluded_points=0,
+               tw_per_level=[x for x in per_level if x["tw_over"] or x["tw_reference_fp32_vs_fp64_over"]],
                seconds=round(time.time() - t0, 1))
     print(json.dumps(res, indent=1))
     if a.out:
