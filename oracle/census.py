@@ -17,6 +17,7 @@ def job(job):
     Runs in a host worker process (never touches HIP)."""
     np.seterr(all="ignore")
     t, q, p = job["t"], job["q"], job["p"]
+    tol = job.get("tol", 1e-4)  # 1e-4 for fp32 outputs, 1e-6 for fp64
     call = {"p3": lambda a, b, c: orc.pipeline_svp_td_rh(a, b, c),
             "wetbulb": lambda a, b, c: (orc.wet_bulb_temperature_from_specific_humidity(a, b, c, "ifs", "newton"),),
             "full": lambda a, b, c: orc.pipeline_full(a, b, c)}[job["kind"]]
@@ -26,7 +27,7 @@ def job(job):
         g64, w64 = g.astype(np.float64), np.asarray(w, np.float64)
         r = np.abs(g64 - w64) / np.abs(w64)
         r = np.where(np.isfinite(r), r, 0.0)
-        entry = dict(max_rel=float(r.max()), over=int((r > 1e-4).sum()), nan_mismatch=int((np.isnan(g64) != np.isnan(w64)).sum()))
+        entry = dict(max_rel=float(r.max()), over=int((r > tol).sum()), nan_mismatch=int((np.isnan(g64) != np.isnan(w64)).sum()))
         if job["tw_index"] == k:
             # the same fp32 inputs through the oracle in fp64: the "true" one-Newton-step answer, and the census of
             # points whose Davies-Jones regime the reference itself decides by rounding
@@ -37,13 +38,13 @@ def job(job):
             ref_self = np.where(np.isfinite(ref_self), ref_self, 0.0)
             band5 = conditioning.newton_regime_boundary("pipeline_full", [t, q, p], {}, 1e-5)
             band6 = conditioning.newton_regime_boundary("pipeline_full", [t, q, p], {}, 1e-6)
-            entry.update(over_vs_fp64_oracle=int((r64 > 1e-4).sum()), max_rel_vs_fp64_oracle=float(r64.max()),
-                         reference_fp32_vs_fp64_over=int((ref_self > 1e-4).sum()),
+            entry.update(over_vs_fp64_oracle=int((r64 > tol).sum()), max_rel_vs_fp64_oracle=float(r64.max()),
+                         reference_fp32_vs_fp64_over=int((ref_self > tol).sum()),
                          band_1e5=int(band5.sum()), band_1e6=int(band6.sum()),
-                         over_outside_band_1e5=int((r[~band5] > 1e-4).sum()),
-                         over_outside_band_1e6=int((r[~band6] > 1e-4).sum()),
-                         over_and_reference_agrees_with_itself=int(((r > 1e-4) & (ref_self <= 1e-4)).sum()),
-                         worst_over=float(r[r > 1e-4].max()) if (r > 1e-4).any() else 0.0)
+                         over_outside_band_1e5=int((r[~band5] > tol).sum()),
+                         over_outside_band_1e6=int((r[~band6] > tol).sum()),
+                         over_and_reference_agrees_with_itself=int(((r > tol) & (ref_self <= tol)).sum()),
+                         worst_over=float(r[r > tol].max()) if (r > tol).any() else 0.0)
         res.append(entry)
     return res
 

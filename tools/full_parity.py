@@ -30,7 +30,10 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--pmode", default="field", choices=["field", "level", "hybrid"],
                     help="pressure as a full field, as the 137-level vector, or formed in the kernel from sp + A/B tables")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     a = ap.parse_args()
+    dt = dt if a.dtype == "f32" else np.float64
+    tol = 1e-4 if a.dtype == "f32" else 1e-6
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))
     pool = mp.get_context("fork").Pool(cores)  # before HIP is initialised in this process
 
@@ -40,30 +43,30 @@ def main():
     nlev, inner = a.levels, 1800 * 3600
     n = nlev * inner
     lib = _ffi.lib()
-    t, q, p = (ekm_hip.DeviceArray.empty((n,), np.float32) for _ in range(3))
+    t, q, p = (ekm_hip.DeviceArray.empty((n,), dt) for _ in range(3))
     plev_host = sp_host = Ah = Bh = None
     if a.pmode == "hybrid":
         from oracle import vertical_oracle as vo
 
         g = np.load(os.path.join(ROOT, "tests", "golden", "vertical_golden.npz"))
-        Ah, Bh = (g[f"coef.137.{k}"][137 - nlev:].astype(np.float32) for k in "AB")
-        sp_host = (101325.0 * (1.0 - 0.35 * np.random.default_rng(20260313).random(inner) ** 3)).astype(np.float32)
+        Ah, Bh = (g[f"coef.137.{k}"][137 - nlev:].astype(dt) for k in "AB")
+        sp_host = (101325.0 * (1.0 - 0.35 * np.random.default_rng(20260313).random(inner) ** 3)).astype(dt)
         hp = ekm_hip.HybridPressure(Ah, Bh, ekm_hip.to_device(sp_host))
         # t, q drawn around the hybrid-level pressure (materialised once for the generator, then dropped)
-        _ffi.check(lib.ekm_pressure_on_hybrid_levels_f32(0, None, ekm_hip.to_device(Ah).ptr, ekm_hip.to_device(Bh).ptr,
+        _ffi.check(getattr(lib, f"ekm_pressure_on_hybrid_levels_{a.dtype}")(0, None, ekm_hip.to_device(Ah).ptr, ekm_hip.to_device(Bh).ptr,
                                                          hp.sp.ptr, inner, nlev, None, None, 1, float(np.log(2)), p.ptr,
                                                          None, None, None))
-        _ffi.check(lib.ekm_synth_fill_given_p_f32(0, None, t.ptr, q.ptr, p.ptr, 0, n, 20260313))
+        _ffi.check(getattr(lib, f"ekm_synth_fill_given_p_{a.dtype}")(0, None, t.ptr, q.ptr, p.ptr, 0, n, 20260313))
         ekm_hip.synchronize()
         outs = thermo.pipeline_full(t.reshape(nlev, inner), q.reshape(nlev, inner), hp)
     elif a.pmode == "level":
-        plev = ekm_hip.DeviceArray.empty((nlev,), np.float32)
-        _ffi.check(lib.ekm_synth_levels_f32(0, None, plev.ptr, nlev))
-        _ffi.check(lib.ekm_synth_fill_f32(0, None, t.ptr, q.ptr, None, 0, n, inner, nlev, 20260313))
+        plev = ekm_hip.DeviceArray.empty((nlev,), dt)
+        _ffi.check(getattr(lib, f"ekm_synth_levels_{a.dtype}")(0, None, plev.ptr, nlev))
+        _ffi.check(getattr(lib, f"ekm_synth_fill_{a.dtype}")(0, None, t.ptr, q.ptr, None, 0, n, inner, nlev, 20260313))
         plev_host = plev.to_host()
         outs = thermo.pipeline_full(t.reshape(nlev, inner), q.reshape(nlev, inner), plev.reshape(nlev, 1))
     else:
-        _ffi.check(lib.ekm_synth_fill_f32(0, None, t.ptr, q.ptr, p.ptr, 0, n, inner, nlev, 20260313))
+        _ffi.check(getattr(lib, f"ekm_synth_fill_{a.dtype}")(0, None, t.ptr, q.ptr, p.ptr, 0, n, inner, nlev, 20260313))
         outs = thermo.pipeline_full(t, q, p)
     outs = tuple(o.ravel() for o in outs)
     ekm_hip.synchronize()
@@ -77,27 +80,27 @@ def main():
         base = lev * inner
         host = [x.flat_slice(base, base + inner).to_host() for x in (t, q, p) + tuple(outs)]
         if a.pmode == "level":  # the oracle gets the level's pressure as the reference would: broadcast over the level
-            host[2] = np.full(inner, plev_host[lev], np.float32)
+            host[2] = np.full(inner, plev_host[lev], dt)
         elif a.pmode == "hybrid":  # ... or the hybrid definition evaluated by the (pinned) vertical oracle
             host[2] = np.ascontiguousarray(vo.pressure_on_hybrid_levels(Ah[lev:lev + 2], Bh[lev:lev + 2], sp_host)[0]
-                                           .astype(np.float32))
+                                           .astype(dt))
         jobs = []
         for lo in range(0, inner, chunk):
             hi = min(lo + chunk, inner)
             jobs.append(dict(kind="full", t=host[0][lo:hi], q=host[1][lo:hi], p=host[2][lo:hi],
-                             got=[h[lo:hi] for h in host[3:]], tw_index=5))
+                             got=[h[lo:hi] for h in host[3:]], tw_index=5, tol=tol))
         parts.append(census.merge(pool.map(census.job, jobs)))
         per_level.append(dict(level=lev, p_mean=float(np.mean(host[2], dtype=np.float64)), tw_over=parts[-1][5]["over"],
                               tw_reference_fp32_vs_fp64_over=parts[-1][5]["reference_fp32_vs_fp64_over"],
                               tw_max_rel=parts[-1][5]["max_rel"]))
         if lev % 8 == 0:
             tw = census.merge(parts)[5]
-            print(f"level {lev + 1}/{nlev}  {time.time() - t0:.0f} s  tw: beyond 1e-4 so far {tw['over']} "
+            print(f"level {lev + 1}/{nlev}  {time.time() - t0:.0f} s  tw: beyond the bar so far {tw['over']} "
                   f"(reference fp32 vs fp64: {tw['reference_fp32_vs_fp64_over']})", flush=True)
     total = dict(zip(NAMES, census.merge(parts)))
     npts = n
     pool.close()
-    res = dict(points=npts, levels=nlev, p_mode=a.pmode, tolerance=1e-4, outputs=total, excluded_points=0,
+    res = dict(points=npts, levels=nlev, p_mode=a.pmode, dtype=a.dtype, tolerance=tol, outputs=total, excluded_points=0,
                tw_per_level=[x for x in per_level if x["tw_over"] or x["tw_reference_fp32_vs_fp64_over"]],
                seconds=round(time.time() - t0, 1))
     print(json.dumps(res, indent=1))
