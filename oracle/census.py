@@ -49,6 +49,37 @@ def job(job):
     return res
 
 
+def bisect_job(job):
+    """Bisection wet-bulb (the reference's default t_method) on one slab: job = dict(t, q, p, got).  The result is
+    quantised to 120/4096 K, so the census is in quanta: how many points equal the fp32 reference bit for bit, how many
+    sit one / two / more quanta away, NaN-pattern differences, and how many of the non-identical points are ones
+    where the reference's own residual is below fp32 noise at some step (oracle/conditioning.py, threshold 3e-6) or
+    where its fp32 and fp64 runs disagree."""
+    np.seterr(all="ignore")
+    t, q, p, got = job["t"], job["q"], job["p"], job["got"]
+    want = orc.wet_bulb_temperature_from_specific_humidity(t, q, p, "ifs", "bisect")
+    g64, w64 = got.astype(np.float64), np.asarray(want, np.float64)
+    quantum = 120.0 / 4096.0
+    nanmm = np.isnan(g64) != np.isnan(w64)
+    d = np.abs(g64 - w64) / quantum
+    d = np.where(np.isfinite(d), d, 0.0)
+    differ = (d > 0) | nanmm
+    res = dict(n=int(t.size), identical=int((~differ).sum()), one_quantum=int(((d > 0) & (d <= 1.0001)).sum()),
+               two_quanta=int(((d > 1.0001) & (d <= 2.0001)).sum()), more=int((d > 2.0001).sum()),
+               nan_mismatch=int(nanmm.sum()), max_quanta=float(d.max()))
+    if differ.any():  # classify the differing points only (the fp64 reference run is the expensive part)
+        idx = np.flatnonzero(differ)
+        noisy = conditioning.bisect_sign_noise("wet_bulb_temperature_from_specific_humidity", [t[idx], q[idx], p[idx]], {}, 3e-6)
+        w_true = orc.wet_bulb_temperature_from_specific_humidity(*(x[idx].astype(np.float64) for x in (t, q, p)), "ifs", "bisect")
+        w32 = w64[idx]
+        unstable = (np.isnan(w32) != np.isnan(w_true)) | (np.abs(w32 - w_true) > 0.5 * quantum)
+        res.update(differ_sign_noise=int(noisy.sum()), differ_reference_unstable=int(unstable.sum()),
+                   differ_unexplained=int((~(noisy | unstable)).sum()))
+    else:
+        res.update(differ_sign_noise=0, differ_reference_unstable=0, differ_unexplained=0)
+    return [res]
+
+
 def merge(parts):
     """Sum the counts and take the maxima of the per-slab results of `job`."""
     total = [dict() for _ in parts[0]]

@@ -31,8 +31,10 @@ def main():
     ap.add_argument("--pmode", default="field", choices=["field", "level", "hybrid"],
                     help="pressure as a full field, as the 137-level vector, or formed in the kernel from sp + A/B tables")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--workload", default="full", choices=["full", "bisect"],
+                    help="full: the six-output pipeline; bisect: wet-bulb by the reference's default bisection (census in quanta)")
     a = ap.parse_args()
-    dt = dt if a.dtype == "f32" else np.float64
+    dt = np.float32 if a.dtype == "f32" else np.float64
     tol = 1e-4 if a.dtype == "f32" else 1e-6
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))
     pool = mp.get_context("fork").Pool(cores)  # before HIP is initialised in this process
@@ -65,6 +67,9 @@ def main():
         _ffi.check(getattr(lib, f"ekm_synth_fill_{a.dtype}")(0, None, t.ptr, q.ptr, None, 0, n, inner, nlev, 20260313))
         plev_host = plev.to_host()
         outs = thermo.pipeline_full(t.reshape(nlev, inner), q.reshape(nlev, inner), plev.reshape(nlev, 1))
+    elif a.workload == "bisect":
+        _ffi.check(getattr(lib, f"ekm_synth_fill_{a.dtype}")(0, None, t.ptr, q.ptr, p.ptr, 0, n, inner, nlev, 20260313))
+        outs = (thermo.wet_bulb_temperature_from_specific_humidity(t, q, p, ept_method="ifs", t_method="bisect"),)
     else:
         _ffi.check(getattr(lib, f"ekm_synth_fill_{a.dtype}")(0, None, t.ptr, q.ptr, p.ptr, 0, n, inner, nlev, 20260313))
         outs = thermo.pipeline_full(t, q, p)
@@ -87,8 +92,18 @@ def main():
         jobs = []
         for lo in range(0, inner, chunk):
             hi = min(lo + chunk, inner)
-            jobs.append(dict(kind="full", t=host[0][lo:hi], q=host[1][lo:hi], p=host[2][lo:hi],
-                             got=[h[lo:hi] for h in host[3:]], tw_index=5, tol=tol))
+            if a.workload == "bisect":
+                jobs.append(dict(t=host[0][lo:hi], q=host[1][lo:hi], p=host[2][lo:hi], got=host[3][lo:hi]))
+            else:
+                jobs.append(dict(kind="full", t=host[0][lo:hi], q=host[1][lo:hi], p=host[2][lo:hi],
+                                 got=[h[lo:hi] for h in host[3:]], tw_index=5, tol=tol))
+        if a.workload == "bisect":
+            parts.append(census.merge(pool.map(census.bisect_job, jobs)))
+            if lev % 8 == 0:
+                b = census.merge(parts)[0]
+                print(f"level {lev + 1}/{nlev}  {time.time() - t0:.0f} s  identical {b['identical']} of {b['n']}, differing "
+                      f"{b['n'] - b['identical']} (unexplained {b['differ_unexplained']})", flush=True)
+            continue
         parts.append(census.merge(pool.map(census.job, jobs)))
         per_level.append(dict(level=lev, p_mean=float(np.mean(host[2], dtype=np.float64)), tw_over=parts[-1][5]["over"],
                               tw_reference_fp32_vs_fp64_over=parts[-1][5]["reference_fp32_vs_fp64_over"],
@@ -97,10 +112,10 @@ def main():
             tw = census.merge(parts)[5]
             print(f"level {lev + 1}/{nlev}  {time.time() - t0:.0f} s  tw: beyond the bar so far {tw['over']} "
                   f"(reference fp32 vs fp64: {tw['reference_fp32_vs_fp64_over']})", flush=True)
-    total = dict(zip(NAMES, census.merge(parts)))
+    total = dict(zip(NAMES if a.workload == "full" else ("tw_bisect",), census.merge(parts)))
     npts = n
     pool.close()
-    res = dict(points=npts, levels=nlev, p_mode=a.pmode, dtype=a.dtype, tolerance=tol, outputs=total, excluded_points=0,
+    res = dict(points=npts, levels=nlev, workload=a.workload, p_mode=a.pmode, dtype=a.dtype, tolerance=tol if a.workload == "full" else "2 quanta of 120/4096 K", outputs=total, excluded_points=0,
                tw_per_level=[x for x in per_level if x["tw_over"] or x["tw_reference_fp32_vs_fp64_over"]],
                seconds=round(time.time() - t0, 1))
     print(json.dumps(res, indent=1))
