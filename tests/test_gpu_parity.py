@@ -624,3 +624,40 @@ def test_level_vector_shapes_pick_the_right_kernel(ek, orc, nlev, inner):
             assert x.shape == t.shape and np.array_equal(x, y, equal_nan=True), (func, nlev, inner)
     want = orc.potential_temperature(t, pl)
     assert_parity(ek.thermo.potential_temperature(t, pl), want, "f32", f"theta level vector {nlev}x{inner}")
+
+
+def test_input_layouts_the_reference_accepts(ek, orc):
+    """The reference takes whatever NumPy broadcasts: strided and transposed views, negative strides, Fortran order,
+    two-way broadcasting, 0-d arrays, mixed precisions, integer arrays, empty arrays.  Same results, shapes, dtypes."""
+    rng = np.random.default_rng(99)
+    t = rng.uniform(220.0, 310.0, (12, 40)).astype(np.float32)
+    q = rng.uniform(1e-5, 0.02, (12, 40)).astype(np.float32)
+    p = rng.uniform(30000.0, 101000.0, (12, 40)).astype(np.float32)
+    T, O = ek.thermo, orc
+    cases = {
+        "strided": (t[::2, ::3], q[::2, ::3], p[::2, ::3]),
+        "transposed": (t.T, q.T, p.T),
+        "reversed": (t[::-1], q[::-1], p[::-1]),
+        "fortran": tuple(np.asfortranarray(x) for x in (t, q, p)),
+        "two-way broadcast": (t[:, :1], q[:1, :], p[:1, :1]),          # (12,1) x (1,40) x (1,1) -> (12,40)
+        "0-d and scalar": (t, np.asarray(np.float32(0.004)), 85000.0),
+        "mixed precision": (t, q.astype(np.float64), p),                # promotes to fp64 as NumPy does
+        "leading ones": (t[None], q[None], p[None]),
+    }
+    for name, (a, b, c) in cases.items():
+        keep = [np.array(x, copy=True) for x in (a, b, c)]
+        got = T.relative_humidity_from_specific_humidity(a, b, c)
+        want = O.relative_humidity_from_specific_humidity(a, b, c)  # the very same objects (a Python float stays weak)
+        assert got.shape == want.shape and got.dtype == want.dtype, (name, got.shape, want.shape, got.dtype, want.dtype)
+        assert_parity(got, want, "f64" if got.dtype == np.float64 else "f32", f"rh {name}")
+        for x, k in zip((a, b, c), keep):
+            assert np.array_equal(np.asarray(x), k), f"{name}: input mutated"
+    ti = np.arange(250, 300, 5)  # integers -> fp64
+    got = T.potential_temperature(ti, np.full(ti.shape, 90000))
+    assert got.dtype == np.float64 and np.allclose(got, O.potential_temperature(ti, np.full(ti.shape, 90000)), rtol=1e-12)
+    for shape in ((0,), (0, 5), (3, 0, 2)):
+        e = np.empty(shape, np.float32)
+        out = T.potential_temperature(e, e)
+        assert out.shape == shape and out.dtype == np.float32
+    es, td, rh = T.pipeline_svp_td_rh(t.T, q.T, p.T)  # multi-output op on views
+    assert es.shape == (40, 12) and np.array_equal(rh, T.relative_humidity_from_specific_humidity(t.T, q.T, p.T))
