@@ -173,3 +173,36 @@ def test_bench_two_ranks_strong_scaling_on_one_device(ek):
     ranks = d["config"]["per_rank"]
     assert [x["points"] for x in ranks] == [8 * 1800 * 3600] * 2 and all(x["kernel_ms"] > 0 for x in ranks)
     assert all(x["hip_device_count"] >= 1 for x in ranks)
+
+
+def test_concurrent_calls_from_several_threads(ek):
+    """The reference's functions are stateless and may be called from several threads; here every thread shares the
+    block cache, the default stream and the library's device table.  Results must equal the serial ones."""
+    import threading
+
+    t, q, p = _fields(4, 1 << 18)
+    jobs = [("pipeline_full", (t, q, p), {}), ("potential_temperature", (t, p), {}),
+            ("wet_bulb_temperature_from_specific_humidity", (t, q, p), {"t_method": "newton"}),
+            ("saturation_vapour_pressure", (t,), {"phase": "mixed"}), ("pipeline_svp_td_rh", (t, q, p), {}),
+            ("wet_bulb_temperature_from_specific_humidity", (t, q, p), {})]
+    want = [getattr(ek.thermo, f)(*a, **k) for f, a, k in jobs]
+    got, errors = [[None] * 6 for _ in jobs], []
+
+    def work(i):
+        f, a, k = jobs[i]
+        try:
+            for rep in range(6):
+                got[i][rep] = getattr(ek.thermo, f)(*a, **k)
+        except BaseException as exc:
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for w, reps in zip(want, got):
+        for g in reps:
+            for a, b in zip(w if isinstance(w, tuple) else (w,), g if isinstance(g, tuple) else (g,)):
+                assert np.array_equal(a, b, equal_nan=True)
