@@ -305,12 +305,14 @@ def main():
         _ffi.check(getattr(lib, f"ekm_synth_levels_{args.dtype}")(dev, None, plev.ptr, nlev))
         hyb = None
         if args.pmode == "hybrid" or args.workload == "hybrid_levels":
-            # IFS L137 half-level tables (data recorded from the reference's conf/ifs_levels_conf.json); a level
+            # IFS L137 half-level tables (ekm_hip.vertical.hybrid_level_parameters, shipped inside the package); a level
             # shard takes the half levels lev0 .. lev1 of the table, a column shard its columns of sp
             assert nlev <= 137, "hybrid mode: at most the 137 IFS levels"
-            g = np.load(os.path.join(ROOT, "tests", "golden", "vertical_golden.npz"))
-            A = g["coef.137.A"][137 - nlev:][lev0:lev1 + 1]
-            B = g["coef.137.B"][137 - nlev:][lev0:lev1 + 1]
+            from ekm_hip.vertical import hybrid_level_parameters
+
+            A137, B137 = hybrid_level_parameters(137, model="ifs")
+            A = A137[137 - nlev:][lev0:lev1 + 1]
+            B = B137[137 - nlev:][lev0:lev1 + 1]
             rng = np.random.default_rng(20260313 if args.scaling == "strong" else seed)
             sp_host = (101325.0 * (1.0 - 0.35 * rng.random(INNER) ** 3)).astype(np_dtype)  # mostly near sea level, some orography
             sp_host = np.ascontiguousarray(sp_host[col0:col1])

@@ -141,10 +141,14 @@ enum { GEO_THICKNESS = 0, GEO_GEOPOTENTIAL = 1, GEO_H_GEOM_SEA = 2, GEO_H_GP_SEA
 #endif
 constexpr int kGeoThreads = EKM_GEO_THREADS;
 
-template <class T, bool VEC>
+// AD: alpha and delta are given as fields (outputs of pressure_on_hybrid_levels the caller already holds,
+// vertical.py:815-893) and streamed like t and q instead of being formed from A, B, sp (which are then unused).
+template <class T, bool VEC, bool AD>
 __global__ __launch_bounds__(kGeoThreads) void geopotential_columns(const T* __restrict__ A, const T* __restrict__ B,
                                                                 const T* __restrict__ sp, const T* __restrict__ zs,
                                                                 const T* __restrict__ t, const T* __restrict__ q,
+                                                                const T* __restrict__ alpha_in,
+                                                                const T* __restrict__ delta_in,
                                                                 unsigned long long npts, unsigned nfull,
                                                                 unsigned k_lo, unsigned k_hi, int top_is_zero,
                                                                 T alpha_top, int mode, T* __restrict__ out) {
@@ -163,7 +167,10 @@ __global__ __launch_bounds__(kGeoThreads) void geopotential_columns(const T* __r
     }
     return v;
   };
-  const Vec s = get(sp, 0);
+  Vec s;
+#pragma unroll
+  for (int j = 0; j < V; ++j) s[j] = T(1);
+  if (!AD) s = get(sp, 0);
   Vec z0, hs;
 #pragma unroll
   for (int j = 0; j < V; ++j) z0[j] = hs[j] = T(0);
@@ -198,15 +205,24 @@ __global__ __launch_bounds__(kGeoThreads) void geopotential_columns(const T* __r
       for (int j = 0; j < V; ++j) acc[j] = (i0 + j < npts) ? src[j] : T(0);
     }
   }
-  Vec phn = A[k_hi] + B[k_hi] * s;  // lower half level of the current layer
+  Vec phn = s, ph = s;
+  if (!AD) phn = A[k_hi] + B[k_hi] * s;  // lower half level of the current layer
   for (unsigned kk = k_hi; kk-- > k_lo;) {
-    const Vec ph = A[kk] + B[kk] * s;
+    if (!AD) ph = A[kk] + B[kk] * s;
     const Vec tk = get(t, kk), qk = get(q, kk);
+    Vec al = s, de = s;
+    if (AD) {
+      al = get(alpha_in, kk);
+      de = get(delta_in, kk);
+    }
     Vec o;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       T d, a;
-      if (kk == 0 && top_is_zero) {
+      if (AD) {
+        d = de[j];
+        a = al[j];
+      } else if (kk == 0 && top_is_zero) {
         d = log(phn[j] / T(0.1));
         a = alpha_top;
       } else {
@@ -250,9 +266,13 @@ __global__ __launch_bounds__(kGeoThreads) void geopotential_columns(const T* __r
 template <class T>
 static int launch_geopotential(int dev, void* stream, const T* A, const T* B, const T* sp, const T* zs, const T* t,
                                const T* q, size_t npts, uint32_t nfull, int top_is_zero, T alpha_top, int mode,
-                               T* out) {
+                               T* out, const T* alpha_in = nullptr, const T* delta_in = nullptr) {
   if (npts == 0 || nfull == 0) return EKM_OK;
-  if (!A || !B || !sp || !t || !q || !out) return set_error(EKM_ERR_ARG, "geopotential_on_hybrid_levels: null pointer");
+  const bool ad = alpha_in || delta_in;
+  if (ad && (!alpha_in || !delta_in || !t || !q || !out))
+    return set_error(EKM_ERR_ARG, "geopotential_thickness_from_alpha_delta: null pointer");
+  if (!ad && (!A || !B || !sp || !t || !q || !out))
+    return set_error(EKM_ERR_ARG, "geopotential_on_hybrid_levels: null pointer");
   if (mode < 0 || mode > 5) return set_error(EKM_ERR_ENUM, "geopotential_on_hybrid_levels: mode=%d", mode);
   if (mode != GEO_THICKNESS && mode != GEO_H_GP_GROUND && !zs)
     return set_error(EKM_ERR_ARG, "geopotential_on_hybrid_levels: this mode needs the surface geopotential zs");
@@ -260,7 +280,8 @@ static int launch_geopotential(int dev, void* stream, const T* A, const T* B, co
   if (rc != EKM_OK) return rc;
   constexpr int V = VecOf<T>::N;
   int vec_ok = (npts % V == 0);
-  for (const void* ptr : {(const void*)sp, (const void*)zs, (const void*)t, (const void*)q, (const void*)out})
+  for (const void* ptr : {(const void*)sp, (const void*)zs, (const void*)t, (const void*)q, (const void*)out,
+                          (const void*)alpha_in, (const void*)delta_in})
     if (ptr && reinterpret_cast<uintptr_t>(ptr) % 16) vec_ok = 0;
   const unsigned long long nchunk = (npts + V - 1) / V;
   const unsigned long long grid = (nchunk + kGeoThreads - 1) / kGeoThreads;
@@ -271,14 +292,18 @@ static int launch_geopotential(int dev, void* stream, const T* A, const T* B, co
   for (unsigned c = 0; c < nchunks; ++c) {
     const unsigned k_hi = nfull - (unsigned)((unsigned long long)nfull * c / nchunks);
     const unsigned k_lo = nfull - (unsigned)((unsigned long long)nfull * (c + 1) / nchunks);
-    if (vec_ok)
-      hipLaunchKernelGGL((geopotential_columns<T, true>), dim3((unsigned)grid), dim3(kGeoThreads), 0,
-                         static_cast<hipStream_t>(stream), A, B, sp, zs, t, q, (unsigned long long)npts, nfull, k_lo,
-                         k_hi, top_is_zero, alpha_top, mode, out);
-    else
-      hipLaunchKernelGGL((geopotential_columns<T, false>), dim3((unsigned)grid), dim3(kGeoThreads), 0,
-                         static_cast<hipStream_t>(stream), A, B, sp, zs, t, q, (unsigned long long)npts, nfull, k_lo,
-                         k_hi, top_is_zero, alpha_top, mode, out);
+    const dim3 g((unsigned)grid), b(kGeoThreads);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const unsigned long long np_ = npts;
+#define EKM_GEO_LAUNCH(VEC_, AD_)                                                                                   \
+  hipLaunchKernelGGL((geopotential_columns<T, VEC_, AD_>), g, b, 0, st, A, B, sp, zs, t, q, alpha_in, delta_in, np_, \
+                     nfull, k_lo, k_hi, top_is_zero, alpha_top, mode, out)
+    if (ad) {
+      if (vec_ok) EKM_GEO_LAUNCH(true, true); else EKM_GEO_LAUNCH(false, true);
+    } else {
+      if (vec_ok) EKM_GEO_LAUNCH(true, false); else EKM_GEO_LAUNCH(false, false);
+    }
+#undef EKM_GEO_LAUNCH
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(EKM_ERR_HIP, "geopotential_columns launch: %s", hipGetErrorString(e));
@@ -355,6 +380,20 @@ int ekm_geopotential_on_hybrid_levels_f64(int dev, void* stream, const double* A
                                           const double* zs, const double* t, const double* q, size_t npts,
                                           uint32_t nfull, int top_is_zero, double alpha_top, int mode, double* out) {
   return ekm::launch_geopotential<double>(dev, stream, A, B, sp, zs, t, q, npts, nfull, top_is_zero, alpha_top, mode, out);
+}
+
+int ekm_geopotential_thickness_from_alpha_delta_f32(int dev, void* stream, const float* t, const float* q,
+                                                    const float* alpha, const float* delta, size_t npts, uint32_t nfull,
+                                                    float* out) {
+  return ekm::launch_geopotential<float>(dev, stream, nullptr, nullptr, nullptr, nullptr, t, q, npts, nfull, 0, 0.0f,
+                                         ekm::GEO_THICKNESS, out, alpha, delta);
+}
+
+int ekm_geopotential_thickness_from_alpha_delta_f64(int dev, void* stream, const double* t, const double* q,
+                                                    const double* alpha, const double* delta, size_t npts,
+                                                    uint32_t nfull, double* out) {
+  return ekm::launch_geopotential<double>(dev, stream, nullptr, nullptr, nullptr, nullptr, t, q, npts, nfull, 0, 0.0,
+                                          ekm::GEO_THICKNESS, out, alpha, delta);
 }
 
 int ekm_any_le_f32(int dev, void* stream, const float* sp, size_t n, float a0, float b0, float thresh, int32_t* flag) {

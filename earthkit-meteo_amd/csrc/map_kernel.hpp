@@ -562,9 +562,11 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
     if (reinterpret_cast<uintptr_t>(outs[o]) % 16) aligned = false;
   }
   a.vec_ok = aligned ? 1 : 0;
-  if ((size_t)lds_elems * sizeof(T) > kMaxLdsBytes)
-    return set_error(EKM_ERR_ARG, "level vectors need %zu B of LDS (max %u)", (size_t)lds_elems * sizeof(T),
-                     kMaxLdsBytes);
+  // the op's own per-workgroup table (static LDS, OpTable) shares the 64 KiB with the staged level vectors
+  constexpr size_t kTableBytes = (size_t)OpTable<Op>::elems * sizeof(T);
+  if ((size_t)lds_elems * sizeof(T) + kTableBytes > kMaxLdsBytes)
+    return set_error(EKM_ERR_ARG, "level vectors need %zu B of LDS (max %zu beside this op's %zu-B table)",
+                     (size_t)lds_elems * sizeof(T), (size_t)kMaxLdsBytes - kTableBytes, kTableBytes);
 
   const unsigned long long nchunk = (n + V - 1) / V;
   const unsigned long long ntile = (nchunk + kThreads - 1) / kThreads;
@@ -624,7 +626,9 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
           while ((ntx + band - 1) / band > 65535ull) band *= 2;
         }
         const dim3 g((unsigned)band, (unsigned)gy, (unsigned)((ntx + band - 1) / band));
-        const bool al = aligned && inner % V == 0;
+        // rows start 16-B aligned when the row length is a multiple of the vector width -- or when there is only one
+        // row (a scalar operand with any n): its ragged end is handled by the kernel's own `col + V <= rowlen` test
+        const bool al = aligned && (inner % V == 0 || nlev == 1);
         if (pm == EKM_HYBRID_FULL) {
           if (al)
             hipLaunchKernelGGL((map_levels<Op, T, PM_HYBRID, true>), g, dim3(kThreads), 0, s, la);

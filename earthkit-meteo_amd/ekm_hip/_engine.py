@@ -23,7 +23,7 @@ from .device import DeviceArray, current_device, current_stream
 from .vertical import HybridPressure
 
 _F32, _F64 = np.dtype(np.float32), np.dtype(np.float64)
-_MAX_LDS_BYTES = 64 * 1024
+_MAX_LDS_BYTES = 32 * 1024  # of the kernels' 64 KiB: an op's own LDS table (bisection: up to 32 KiB in fp64) shares it
 _MIN_VEC = 4  # a LEVEL operand must span at least one 16-B chunk per level
 _PRETOUCH_BYTES = 8 << 20
 _STREAM_BYTES = 256 << 20  # total input bytes from which a single-GPU NumPy call is streamed in slices
@@ -270,10 +270,11 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
         plans.append(pl)
     outs = [np.empty(shape, out_dtype) for _ in range(nout)]
     errors = []
-    slices, ready = [], {}  # per device: its slices in order; per slice: "its result pages exist" event
+    slices, ready, max_rows = [], {}, []  # per device: its slices in order (and the longest); per slice: "its result pages exist" event
     for (lo, hi), (lanes, nslices) in zip(blocks, plans):
         mine = [(lo + a, lo + b) for a, b in leading_axis_bounds(hi - lo, nslices) if b > a]
         slices.append(mine)
+        max_rows.append(max(b - a for a, b in mine))
         for sl in mine:
             ready[sl] = threading.Event()
 
@@ -293,7 +294,7 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
             for ev in ready.values():
                 ev.set()
 
-    def uploader(dev, mine, depth, slots, handoff):
+    def uploader(dev, mine, depth, slots, handoff, most):
         # ONE host-to-device copy in flight per GPU: concurrent pageable uploads collapse (207 MB in 1 / 2 / 4 / 8
         # threads: 48 / 53 / 19 / 16 GB/s), while an upload and a download run together at full rate (PCIe duplex)
         try:
@@ -306,7 +307,10 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
                 # operands that span the leading axis get the matching slice; everything else is passed as
                 # the caller gave it (a Python scalar must stay a weak scalar for the dtype promotion)
                 part = [h[lo:hi] if sp else a for h, a, sp in zip(host, args, spans)]
-                handoff.put(((lo, hi), _submit(name, part, ints, eps, dtype, host_out=[o[lo:hi] for o in outs])))
+                # slices differ by one row: every slice's device blocks are sized for the LONGEST slice, so a lane takes
+                # back exactly the blocks it released (same bucket) and the footprint stays lanes x slice, live + cached
+                handoff.put(((lo, hi), _submit(name, part, ints, eps, dtype, host_out=[o[lo:hi] for o in outs],
+                                               reserve_rows=(hi - lo, most))))
         except BaseException as exc:  # surfaced in the calling thread
             errors.append(exc)
         finally:
@@ -335,9 +339,9 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
                 slots.release()
 
     threads = [threading.Thread(target=toucher)]
-    for dev, mine, (depth, _n) in zip(devs, slices, plans):
+    for dev, mine, (depth, _n), most in zip(devs, slices, plans, max_rows):
         slots, handoff = threading.Semaphore(depth), queue.Queue()
-        threads.append(threading.Thread(target=uploader, args=(dev, mine, depth, slots, handoff)))
+        threads.append(threading.Thread(target=uploader, args=(dev, mine, depth, slots, handoff, most)))
         threads.append(threading.Thread(target=downloader, args=(dev, slots, handoff)))
     for th in threads:
         th.start()
@@ -354,15 +358,23 @@ class _Pending:
     __slots__ = ("plan", "results", "temps", "host_out", "internal_out", "toucher", "stream")
 
 
+def _reserved(nbytes, reserve_rows):
+    if not reserve_rows or reserve_rows[0] <= 0:
+        return 0
+    rows, most = reserve_rows
+    return -(-nbytes // rows) * most if nbytes % rows == 0 else 0  # only blocks that scale with the slice's rows
+
+
 def _run_single(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=None):
     """One launch.  `host_out` (caller-owned NumPy destinations, e.g. slices of a result array) receives the
     outputs directly; `toucher` is a thread prefaulting them, joined before anything is downloaded."""
     return _collect(_submit(name, args, ints, eps, dtype, host_out, toucher))
 
 
-def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=None):
+def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=None, reserve_rows=None):
     """Upload what lives on the host, launch, return without waiting for the kernel (the uploads themselves are
-    synchronous copies on the current stream)."""
+    synchronous copies on the current stream).  `reserve_rows` = (rows of this slice, rows of the longest slice):
+    field-sized device blocks are reserved at the longest slice's size (streamed path)."""
     ins, outs, int_names, has_eps = OPS[name]
     assert len(args) == len(ins) and len(ints) == len(int_names)
     plan = _Plan(args, dtype)
@@ -408,12 +420,14 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
             if cls is None:
                 h = np.broadcast_to(h.reshape(_padded(h.shape, len(plan.shape))), plan.shape)
                 cls = (_ffi.FIELD, 0, 0)
-            darr = DeviceArray.from_host(np.ascontiguousarray(h, dtype=plan.dtype), device=dev)
+            darr = DeviceArray.from_host(np.ascontiguousarray(h, dtype=plan.dtype), device=dev,
+                                         capacity=_reserved(h.size * plan.dtype.itemsize, reserve_rows))
             temps.append(darr)
         # .on(stream): an input last used on another stream makes this stream wait for that work (device-side)
         operands.append(_ffi.Operand(darr.on(stream), cls[0], 0, cls[1], cls[2]))
 
-    results = [DeviceArray.empty(plan.shape, plan.dtype, dev) for _ in outs]
+    results = [DeviceArray.empty(plan.shape, plan.dtype, dev, capacity=_reserved(plan.n * plan.dtype.itemsize, reserve_rows))
+               for _ in outs]
     cargs = [dev, stream] + [C.byref(o) for o in operands] + [int(v) for v in ints]
     if has_eps:
         cargs.append(float(eps))

@@ -75,6 +75,7 @@ def _signatures():
             [i, vp, vp, vp, vp, sz, u32, vp, vp, i, real, vp, vp, vp, vp], i)
         sig[f"ekm_any_le_{tag}"] = ([i, vp, vp, sz, real, real, real, vp], i)
         sig[f"ekm_geopotential_on_hybrid_levels_{tag}"] = ([i, vp, vp, vp, vp, vp, vp, vp, sz, u32, i, real, i, vp], i)
+        sig[f"ekm_geopotential_thickness_from_alpha_delta_{tag}"] = ([i, vp, vp, vp, vp, vp, sz, u32, vp], i)
     for name, (ins, outs, ints, has_eps) in OPS.items():
         for tag, real in (("f32", C.c_float), ("f64", C.c_double)):
             args = [i, vp] + [C.POINTER(Operand)] * len(ins) + [i] * len(ints)

@@ -10,6 +10,7 @@ import ctypes as C
 import itertools
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -102,7 +103,17 @@ def stream_destroy(stream, dev=None):
     dev = current_device() if dev is None else dev
     lib = _ffi.lib()
     _ffi.check(lib.ekm_stream_sync(dev, stream))
+    # Arrays computed on this stream outlive it ("compute on a temporary stream, destroy it, keep the results"):
+    # all their work is complete now, so they are re-filed under the default stream -- a later use on any stream
+    # must not record an event on the destroyed handle.
+    for owner in _owners_snapshot():
+        if owner.stream == stream and owner.device == dev:
+            with owner._lock:
+                if owner.stream == stream:
+                    owner.stream = None
     _cache.drain(device=dev, stream=stream)
+    if current_stream() == stream:
+        set_stream(None)
     _ffi.check(lib.ekm_stream_destroy(dev, stream))
 
 
@@ -144,6 +155,7 @@ class _BlockCache:
         self.lock = threading.Lock()
         self.live = {}      # device -> bytes of blocks currently handed out to arrays
         self.peak = {}      # device -> high-water mark of `live` since the last reset
+        self.peak_total = {}  # device -> high-water mark of live + cached (what HIP has actually handed us)
 
     def note(self, device, delta):
         with self.lock:
@@ -151,6 +163,12 @@ class _BlockCache:
             self.live[device] = v
             if v > self.peak.get(device, 0):
                 self.peak[device] = v
+            self._bump(device)
+
+    def _bump(self, device):  # lock held
+        tot = self.live.get(device, 0) + self.bytes.get(device, 0)
+        if tot > self.peak_total.get(device, 0):
+            self.peak_total[device] = tot
 
     @staticmethod
     def bucket(nbytes):
@@ -174,6 +192,7 @@ class _BlockCache:
                 return False
             self.free.setdefault((device, stream, bucket), []).append(ptr)
             self.bytes[device] = self.bytes.get(device, 0) + bucket
+            self._bump(device)
             return True
 
     def drain(self, device=None, stream=Ellipsis):
@@ -193,6 +212,18 @@ class _BlockCache:
 
 
 _cache = _BlockCache()
+_live_owners = weakref.WeakSet()  # every live _Allocation / dlpack._Borrowed (stream_destroy re-files them)
+_owners_lock = threading.Lock()
+
+
+def _register_owner(owner):
+    with _owners_lock:
+        _live_owners.add(owner)
+
+
+def _owners_snapshot():
+    with _owners_lock:
+        return list(_live_owners)
 _STAGGER_MIN_BYTES = 1 << 20   # only blocks of at least 1 MiB (fields) are staggered
 _STAGGER_STEP = 20 << 10       # 20 KiB: 5 x 4 KiB
 _STAGGER_SLOTS = 16
@@ -210,9 +241,10 @@ def memory_stats(dev=None, reset_peak=False):
     dev = current_device() if dev is None else dev
     with _cache.lock:
         out = {"live_bytes": _cache.live.get(dev, 0), "peak_live_bytes": _cache.peak.get(dev, 0),
-               "cached_bytes": _cache.bytes.get(dev, 0)}
+               "cached_bytes": _cache.bytes.get(dev, 0), "peak_footprint_bytes": _cache.peak_total.get(dev, 0)}
         if reset_peak:
             _cache.peak[dev] = _cache.live.get(dev, 0)
+            _cache.peak_total[dev] = _cache.live.get(dev, 0) + _cache.bytes.get(dev, 0)
     return out
 
 
@@ -228,8 +260,9 @@ class _Allocation:
 
     __slots__ = ("ptr", "base", "nbytes", "device", "stream", "bucket", "exported", "_lock", "__weakref__")
 
-    def __init__(self, nbytes, device):
+    def __init__(self, nbytes, device, capacity=0):
         self.device, self.nbytes, self.stream = device, nbytes, current_stream()
+        nbytes = max(nbytes, int(capacity))  # `capacity`: block size to reserve (the streamed path recycles equal blocks)
         # Large blocks start at a staggered offset inside their allocation (a different multiple of 20 KiB for
         # each of 16 consecutive allocations).  hipMalloc returns 2-MiB-aligned blocks, so without it the fields a
         # kernel streams together all sit at the same offset inside their pages and -- depending on where the pages
@@ -253,8 +286,12 @@ class _Allocation:
             ptr = out.value
         self.base, self.ptr = ptr, ptr + stagger
         _cache.note(device, self.bucket)
+        _register_owner(self)
 
     def touch(self, stream):
+        """Atomic for the event record / wait only, not for the launch that follows: ONE array must not be used
+        from two threads on two different streams at the same time (each thread's launch could slip between the
+        other's touch and launch).  Different arrays, or one stream, are fine from any number of threads."""
         with self._lock:
             if stream != self.stream:
                 order_streams(self.device, self.stream, stream)
@@ -286,22 +323,22 @@ class DeviceArray:
 
     # ---- construction ----
     @classmethod
-    def empty(cls, shape, dtype=np.float32, device=None):
+    def empty(cls, shape, dtype=np.float32, device=None, capacity=0):
         dtype = np.dtype(dtype)
         if dtype not in _DTYPES:
             raise TypeError(f"DeviceArray supports float32/float64, not {dtype}")
         shape = (shape,) if np.isscalar(shape) else tuple(int(s) for s in shape)
         device = current_device() if device is None else device
         nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
-        alloc = _Allocation(nbytes, device)
+        alloc = _Allocation(nbytes, device, capacity)
         return cls(alloc, alloc.ptr, shape, dtype, device)
 
     @classmethod
-    def from_host(cls, array, device=None, dtype=None):
+    def from_host(cls, array, device=None, dtype=None, capacity=0):
         a = np.ascontiguousarray(array, dtype=dtype)
         if a.dtype not in _DTYPES:
             a = a.astype(np.float64)
-        out = cls.empty(a.shape, a.dtype, device)
+        out = cls.empty(a.shape, a.dtype, device, capacity)
         out.copy_from_host(a)
         return out
 

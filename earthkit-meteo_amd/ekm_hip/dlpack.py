@@ -8,7 +8,9 @@ import ctypes as C
 
 import numpy as np
 
-from .device import DeviceArray, current_stream, order_streams
+import threading
+
+from .device import DeviceArray, _register_owner, current_device, current_stream, order_streams
 
 kDLROCM = 10
 kDLFloat = 2
@@ -89,11 +91,14 @@ class _Borrowed:
 
     def __init__(self, managed, device, stream):
         self.managed, self.device, self.stream = managed, device, stream
+        self._lock = threading.Lock()
+        _register_owner(self)
 
     def touch(self, stream):
-        if stream != self.stream:
-            order_streams(self.device, self.stream, stream)
-            self.stream = stream
+        with self._lock:
+            if stream != self.stream:
+                order_streams(self.device, self.stream, stream)
+                self.stream = stream
 
     def free(self):
         m, self.managed = self.managed, None
@@ -120,8 +125,12 @@ def from_dlpack(obj):
     ROCm), so it orders its pending work before anything we launch on that stream -- no host wait."""
     stream = current_stream()
     if hasattr(obj, "__dlpack__"):
-        if hasattr(obj, "__dlpack_device__") and obj.__dlpack_device__()[0] != kDLROCM:
-            raise TypeError(f"from_dlpack: device type {obj.__dlpack_device__()[0]} is not ROCm (kDLROCM = {kDLROCM})")
+        if hasattr(obj, "__dlpack_device__"):
+            dl_type, dl_dev = obj.__dlpack_device__()
+            if dl_type != kDLROCM:
+                raise TypeError(f"from_dlpack: device type {dl_type} is not ROCm (kDLROCM = {kDLROCM})")
+            if int(dl_dev) != current_device():
+                stream = None  # our current stream belongs to another GPU: hand over on the tensor's default stream
         try:
             cap = obj.__dlpack__(stream=stream or 0)
         except TypeError:  # a producer without the stream argument

@@ -221,6 +221,49 @@ def _chain(t, q, zs, A, B, sp, alpha_top, mode, vertical_axis):
     return res
 
 
+def relative_geopotential_thickness_on_hybrid_levels_from_alpha_delta(t, q, alpha, delta, vertical_axis=0):
+    """Geopotential thickness between the surface and the hybrid full levels from alpha and delta the caller
+    already holds (outputs of `pressure_on_hybrid_levels`): vertical.py:741-893.  The same bottom-up column scan
+    as `relative_geopotential_thickness_on_hybrid_levels`, with alpha and delta STREAMED (16 B read + 4 B written
+    per point in fp32) instead of formed from A, B, sp.  Result dtype = NumPy promotion of the four inputs (the
+    reference hands out fp64 alpha / delta whatever the input dtype, so fp32 t, q with those give fp64)."""
+    arrs = dict(t=t, q=q, alpha=alpha, delta=delta)
+    on_device = any(isinstance(v, DeviceArray) for v in arrs.values())
+    if on_device and vertical_axis != 0:
+        raise ValueError("DeviceArray input: fields are level-major, vertical_axis must be 0")
+    host = {k: (v if isinstance(v, DeviceArray) else np.asarray(v)) for k, v in arrs.items()}
+    if vertical_axis != 0:
+        host = {k: np.moveaxis(v, vertical_axis, 0) for k, v in host.items()}
+    out_dtype = np.result_type(*[v.dtype for v in host.values()])
+    if out_dtype.kind != "f":
+        out_dtype = _F64
+    dtype = _F32 if out_dtype in (_F32, np.dtype(np.float16)) else _F64
+    shape = tuple(host["t"].shape)
+    if len(shape) == 0 or any(tuple(v.shape) != shape for v in host.values()):
+        raise ValueError("t, q, alpha and delta must have the same shape [levels, ...]: "
+                         + ", ".join(f"{k} {tuple(v.shape)}" for k, v in host.items()))
+    nlev, npts = shape[0], int(np.prod(shape[1:], dtype=np.int64))
+    device = next((v.device for v in host.values() if isinstance(v, DeviceArray)), current_device())
+    stream = current_stream()
+    d = {}
+    for k, v in host.items():
+        d[k] = v if isinstance(v, DeviceArray) and v.dtype == dtype else DeviceArray.from_host(
+            np.ascontiguousarray(np.asarray(v), dtype=dtype), device)
+        d[k].on(stream)
+    out = DeviceArray.empty(shape, dtype, device)
+    lib = _ffi.lib()
+    tag = "f32" if dtype == _F32 else "f64"
+    _ffi.check(getattr(lib, f"ekm_geopotential_thickness_from_alpha_delta_{tag}")(
+        device, stream, d["t"].ptr, d["q"].ptr, d["alpha"].ptr, d["delta"].ptr, npts, nlev, out.on(stream)))
+    if on_device:
+        return out
+    res = out.to_host().astype(out_dtype, copy=False)
+    out.free()
+    if vertical_axis != 0:
+        res = np.moveaxis(res, 0, vertical_axis)
+    return res
+
+
 def relative_geopotential_thickness_on_hybrid_levels(t, q, A, B, sp, alpha_top="ifs", vertical_axis=0):
     """Geopotential thickness between the surface and the hybrid full levels (vertical.py:894-994)."""
     return _chain(t, q, None, A, B, sp, alpha_top, _GEO_MODE["thickness"], vertical_axis)
@@ -238,6 +281,35 @@ def height_on_hybrid_levels(t, q, zs, A, B, sp, alpha_top="ifs", h_type="geometr
         raise ValueError(f"Unknown '{h_reference=}'. Use 'sea' or 'ground'.")
     key = ("geometric" if h_type == "geometric" else "geopotential", h_reference)
     return _chain(t, q, zs, A, B, sp, alpha_top, _GEO_MODE[key], vertical_axis)
+
+
+_LEVEL_TABLES = None
+
+
+def hybrid_level_parameters(n_levels, model="ifs"):
+    """The A and B half-level coefficients of a hybrid-level configuration (vertical/array/hybrid.py:40-102):
+    two float64 arrays of length n_levels + 1; `model="ifs"` with 91 or 137 levels, same errors as the
+    reference.  The tables are the constant data of the reference's conf/ifs_levels_conf.json, recorded into
+    ekm_hip/data/ifs_levels.npz by tests/golden/gen_golden_vertical.py and shipped inside the package."""
+    global _LEVEL_TABLES
+    import os
+
+    if _LEVEL_TABLES is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "ifs_levels.npz")
+        with np.load(path) as f:
+            tabs = {}
+            for key in f.files:
+                mdl, n, which = key.split(".")
+                tabs.setdefault(mdl, {}).setdefault(n, {})[which] = f[key]
+        _LEVEL_TABLES = tabs
+    model = model.lower()
+    n_levels = str(n_levels)
+    if model in _LEVEL_TABLES:
+        if n_levels in _LEVEL_TABLES[model]:
+            c = _LEVEL_TABLES[model][n_levels]
+            return c["A"], c["B"]
+        raise ValueError(f"Hybrid level parameters not available for {n_levels} levels in model '{model}'.")
+    raise ValueError(f"Model '{model}' not recognized for hybrid level parameters.")
 
 
 class HybridPressure:

@@ -20,9 +20,8 @@ from ekm_hip import thermo, vertical  # noqa: E402
 
 
 def main(nlat=181, nlon=360):
-    # IFS L137 half-level coefficients (data shipped with the tests; in production: your GRIB headers)
-    g = np.load(os.path.join(ROOT, "tests", "golden", "vertical_golden.npz"))
-    A, B = g["coef.137.A"], g["coef.137.B"]
+    # IFS L137 half-level coefficients (the same call as earthkit.meteo.vertical.array.hybrid_level_parameters)
+    A, B = vertical.hybrid_level_parameters(137, model="ifs")
     rng = np.random.default_rng(0)
     sp = (101325.0 * (1.0 - 0.3 * rng.random((nlat, nlon)) ** 3)).astype(np.float32)
     zs = ((101325.0 - sp) / 1.2).astype(np.float32)   # g*z ~ dp / rho

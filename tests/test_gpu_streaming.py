@@ -54,9 +54,14 @@ def test_streaming_stays_within_a_capped_device_budget(ek, monkeypatch):
     lanes, nslices = _engine.plan_slices(64, 6 * (1 << 19) * 4, cap, overhead=6 * _engine._BLOCK_OVERHEAD)
     assert lanes >= 2 and nslices > lanes  # more slices than lanes: blocks are recycled
     got = ek.thermo.pipeline_svp_td_rh(t, q, p)
-    peak = ek.memory_stats()["peak_live_bytes"] - base
-    print(f"streaming: lanes={lanes} slices={nslices} peak live {peak / 2**20:.1f} MiB of cap {cap / 2**20:.0f} MiB")
+    st = ek.memory_stats()
+    peak, foot = st["peak_live_bytes"] - base, st["peak_footprint_bytes"] - base
+    print(f"streaming: lanes={lanes} slices={nslices} peak live {peak / 2**20:.1f} MiB, peak live + cached "
+          f"{foot / 2**20:.1f} MiB of cap {cap / 2**20:.0f} MiB")
     assert 0 < peak <= cap, (peak, cap)
+    # live + CACHED: slices differ by one row, but every slice reserves the longest slice's block size, so a lane
+    # takes back exactly the blocks it released and nothing piles up in the cache
+    assert foot <= cap, (foot, cap)
     for g, w in zip(got, want):
         assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
     # a budget that cannot hold two single-row slices is an error, not an OOM
@@ -112,6 +117,48 @@ def test_cross_stream_consumer_waits_for_the_producer(ek):
         ek.synchronize()
         ek.stream_destroy(s1)
         ek.stream_destroy(s2)
+
+
+def test_arrays_outlive_the_stream_they_were_computed_on(ek):
+    """"compute on a temporary stream, destroy it, keep the results".  stream_destroy re-files
+    the live arrays of that stream under the default stream (their work is complete after its sync), so a later
+    use on another stream never records an event on the destroyed handle."""
+    t, q, p = _fields(4, 1 << 18)
+    want = _device_path(ek, "potential_temperature", (t, p))[0]
+    s1 = ek.stream_create()
+    ek.set_stream(s1)
+    dt, dp = ek.to_device(t), ek.to_device(p)
+    th = ek.thermo.potential_temperature(dt, dp)          # result (and inputs) last used on s1
+    ek.stream_destroy(s1)                                  # also resets this thread's current stream
+    assert ek.current_stream() is None and th._alloc.stream is None and dt._alloc.stream is None
+    assert np.array_equal(th.to_host(), want)              # default stream
+    s2 = ek.stream_create()
+    try:
+        ek.set_stream(s2)
+        again = ek.thermo.potential_temperature(dt, dp)   # the kept inputs on a third stream
+        assert np.array_equal(again.to_host(), want)
+        assert np.array_equal(th.to_host(), want)
+    finally:
+        ek.set_stream(None)
+        ek.stream_destroy(s2)
+
+
+def test_scalar_pressure_with_ragged_length_takes_the_vector_path(ek):
+    """ADVICE r2 (low): a scalar operand with n % 4 != 0 runs the aligned kernel (its ragged tail element-wise);
+    and a level vector too long for the LDS left beside the bisection table is materialised, not a launch error."""
+    rng = np.random.default_rng(5)
+    for n in (1 << 16) + np.array([1, 2, 3]):
+        t = (250 + 50 * rng.random(int(n))).astype(np.float32)
+        got = ek.thermo.potential_temperature(t, 85000.0)
+        want = ek.thermo.potential_temperature(t, np.full(int(n), 85000.0, np.float32))
+        assert np.array_equal(got, want)
+    nlev = 12000  # 48 KB of fp32 levels: more than the 32 KiB the host layer lets level vectors use
+    t = (250 + 50 * rng.random((nlev, 8))).astype(np.float32)
+    q = np.full_like(t, 0.004)
+    plev = np.linspace(30000, 100000, nlev, dtype=np.float32).reshape(nlev, 1)
+    got = ek.thermo.wet_bulb_temperature_from_specific_humidity(t, q, plev)  # bisection (LDS table) + level vector
+    want = ek.thermo.wet_bulb_temperature_from_specific_humidity(t, q, np.broadcast_to(plev, t.shape).copy())
+    assert np.array_equal(got, want, equal_nan=True)
 
 
 def test_lane_streams_are_bounded_and_releasable(ek):

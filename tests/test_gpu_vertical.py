@@ -153,6 +153,70 @@ def test_geopotential_chain_fixtures_and_device(ek):
         ek.vertical.height_on_hybrid_levels(t, q, zs, A, B, sp, h_reference="moon")
 
 
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_thickness_from_alpha_delta(ek, dt):
+    """vertical.py:815-893: the column scan with alpha and delta streamed instead of formed.  Inputs: the alpha / delta
+    the reference itself was given when the vectors were recorded (fp64 whatever the input dtype)."""
+    npdt = np.float32 if dt == "f32" else np.float64
+    F = ek.vertical.relative_geopotential_thickness_on_hybrid_levels_from_alpha_delta
+    t, q = (G[f"chain.{k}"].astype(npdt) for k in ("t", "q"))
+    al, de = G[f"chain.{dt}.alpha"], G[f"chain.{dt}.delta"]
+    got = F(t, q, al, de)
+    w = G[f"chain.{dt}.from_alpha_delta"]
+    assert got.dtype == w.dtype == np.float64 and got.shape == w.shape  # fp64 alpha / delta promote the result
+    assert np.allclose(got, w, rtol=1e-6, atol=1e-9), np.abs(got - w).max()
+    # the same through the fused producer (A, B, sp): identical up to the fp64 bar
+    if dt == "f64":
+        fused = ek.vertical.relative_geopotential_thickness_on_hybrid_levels(t, q, G["coef.137.A"], G["coef.137.B"],
+                                                                             G["chain.sp"])
+        assert np.allclose(got, fused, rtol=1e-6, atol=1e-9)
+    if dt == "f32":
+        # all-fp32 call: the reference's own fp32 bar for this chain (atol 10 m2/s2, rtol 1e-6) vs its fp32 result
+        g32 = F(t, q, al.astype(npdt), de.astype(npdt))
+        w32 = G["chain.f32.from_alpha_delta_f32ad"]
+        assert g32.dtype == np.float32 and np.allclose(g32, w32, rtol=1e-6, atol=10.0), np.abs(g32 - w32).max()
+        assert np.allclose(g32, G["chain.f64.from_alpha_delta"], rtol=2e-4, atol=0.05)
+        # a contiguous bottom-most level range (47 of 137)
+        sub = F(t[90:], q[90:], al[90:], de[90:])
+        assert np.allclose(sub, G["chain.f32.from_alpha_delta_n47"], rtol=1e-6, atol=1e-9)
+        # device-resident, ragged column count (61): DeviceArray in -> DeviceArray out
+        d = [ek.to_device(x) for x in (t, q, al.astype(npdt), de.astype(npdt))]
+        dev = F(*d)
+        assert isinstance(dev, ek.DeviceArray) and np.array_equal(dev.to_host(), g32, equal_nan=True)
+        # vertical axis last (square-free shape): moved to the front and back
+        tt = np.ascontiguousarray(np.moveaxis(t, 0, -1))
+        moved = F(tt, np.moveaxis(q, 0, -1), np.moveaxis(al, 0, -1), np.moveaxis(de, 0, -1), vertical_axis=1)
+        assert moved.shape == tt.shape and np.allclose(np.moveaxis(moved, -1, 0), got, rtol=1e-12, atol=0)
+    with pytest.raises(ValueError, match="same shape"):
+        F(t, q[:5], al, de)
+
+
+def test_alpha_delta_chain_on_the_device(ek):
+    """pressure_on_hybrid_levels(output=alpha, delta) -> thickness_from_alpha_delta, everything resident in HBM,
+    equals the fused scan on a field large enough for several workgroups (fp32: both within the reference's bar
+    of the fp64 oracle)."""
+    from oracle import vertical_oracle as vo
+
+    A, B = ek.vertical.hybrid_level_parameters(137)
+    rng = np.random.default_rng(8)
+    npts = 5000
+    sp = rng.uniform(5.2e4, 1.04e5, npts)
+    pf = vo.pressure_on_hybrid_levels(A, B, sp)
+    t = np.maximum(288.15 * (np.maximum(pf, 1.0) / 101325.0) ** 0.190263, 190.0) + rng.normal(0, 6, pf.shape)
+    q = np.clip(rng.uniform(0, 1, pf.shape) ** 3 * 0.02 * (pf / 101325.0) ** 2, 1e-7, 0.03)
+    want = vo.relative_geopotential_thickness_on_hybrid_levels(t, q, A, B, sp)
+    for npdt, rtol, atol in ((np.float64, 1e-6, 1e-9), (np.float32, 1e-6, 10.0)):
+        a_, b_ = A.astype(npdt), B.astype(npdt)
+        d_sp, d_t, d_q = (ek.to_device(x.astype(npdt)) for x in (sp, t, q))
+        al, de = ek.vertical.pressure_on_hybrid_levels(a_, b_, d_sp, output=("alpha", "delta"))
+        assert isinstance(al, ek.DeviceArray) and al.dtype == npdt
+        z = ek.vertical.relative_geopotential_thickness_on_hybrid_levels_from_alpha_delta(d_t, d_q, al, de)
+        fused = ek.vertical.relative_geopotential_thickness_on_hybrid_levels(d_t, d_q, a_, b_, d_sp)
+        assert isinstance(z, ek.DeviceArray) and z.shape == (137, npts)
+        assert np.allclose(z.to_host(), want, rtol=rtol, atol=atol), np.abs(z.to_host() - want).max()
+        assert np.allclose(fused.to_host(), want, rtol=rtol, atol=atol)
+
+
 def test_example_model_level_postprocessing(ek):
     import importlib.util
     import os

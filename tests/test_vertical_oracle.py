@@ -102,3 +102,47 @@ def test_chain_oracle_vs_reference_fixtures():
         for hr in ("sea", "ground"):
             h = vo.height_on_hybrid_levels(t, q, zs, A137, B137, sp, h_type=ht, h_reference=hr)
             assert np.allclose(h, G[f"hfix.h_{ht}_{hr}"], atol=1e-8, rtol=1e-6), (ht, hr)
+
+
+def test_from_alpha_delta_oracle_bit_exact():
+    """relative_geopotential_thickness_on_hybrid_levels_from_alpha_delta (vertical.py:815-893) on the alpha / delta
+    the reference was given when the vectors were recorded: fp64; fp32 t, q with the reference's fp64 alpha / delta
+    (promotes to fp64); all-fp32; a 47-level subset."""
+    for dt in ("f64", "f32"):
+        npdt = np.float32 if dt == "f32" else np.float64
+        t, q = (G[f"chain.{k}"].astype(npdt) for k in ("t", "q"))
+        al, de = G[f"chain.{dt}.alpha"], G[f"chain.{dt}.delta"]
+        assert al.dtype == np.float64  # the reference hands these out in fp64 whatever the input dtype
+        got = vo.relative_geopotential_thickness_on_hybrid_levels_from_alpha_delta(t, q, al, de)
+        w = G[f"chain.{dt}.from_alpha_delta"]
+        assert got.dtype == w.dtype and np.array_equal(got, w, equal_nan=True), dt
+    t, q = (G[f"chain.{k}"].astype(np.float32) for k in ("t", "q"))
+    al, de = G["chain.f32.alpha"], G["chain.f32.delta"]
+    got = vo.relative_geopotential_thickness_on_hybrid_levels_from_alpha_delta(t, q, al.astype(np.float32), de.astype(np.float32))
+    assert got.dtype == np.float32 and np.array_equal(got, G["chain.f32.from_alpha_delta_f32ad"], equal_nan=True)
+    got = vo.relative_geopotential_thickness_on_hybrid_levels_from_alpha_delta(t[90:], q[90:], al[90:], de[90:])
+    assert np.array_equal(got, G["chain.f32.from_alpha_delta_n47"], equal_nan=True)
+
+
+def test_hybrid_level_parameters_ship_inside_the_package():
+    """ekm_hip.vertical.hybrid_level_parameters (vertical/array/hybrid.py:40-102): the tables the reference hands
+    out, bit for bit, from a data file INSIDE the product package (no GPU, no library needed); same errors."""
+    import inspect
+
+    from ekm_hip import vertical
+
+    for n in (137, 91):
+        A, B = vertical.hybrid_level_parameters(n)
+        assert A.dtype == np.float64 and A.shape == (n + 1,) and B.shape == (n + 1,)
+        assert np.array_equal(A, G[f"coef.{n}.A"]) and np.array_equal(B, G[f"coef.{n}.B"])
+        A2, _ = vertical.hybrid_level_parameters(str(n), model="IFS")
+        assert np.array_equal(A, A2)
+    with pytest.raises(ValueError, match="not available for 60 levels in model 'ifs'"):
+        vertical.hybrid_level_parameters(60)
+    with pytest.raises(ValueError, match="Model 'gfs' not recognized"):
+        vertical.hybrid_level_parameters(137, model="gfs")
+    assert str(inspect.signature(vertical.hybrid_level_parameters)) == "(n_levels, model='ifs')"
+    assert str(inspect.signature(vertical.relative_geopotential_thickness_on_hybrid_levels_from_alpha_delta)) == \
+        "(t, q, alpha, delta, vertical_axis=0)"
+    path = os.path.join(os.path.dirname(os.path.abspath(vertical.__file__)), "data", "ifs_levels.npz")
+    assert os.path.exists(path) and "tests" not in os.path.relpath(path, os.path.dirname(os.path.dirname(vertical.__file__)))

@@ -50,8 +50,7 @@ def main():
     if a.pmode == "hybrid":
         from oracle import vertical_oracle as vo
 
-        g = np.load(os.path.join(ROOT, "tests", "golden", "vertical_golden.npz"))
-        Ah, Bh = (g[f"coef.137.{k}"][137 - nlev:].astype(dt) for k in "AB")
+        Ah, Bh = (x[137 - nlev:].astype(dt) for x in ekm_hip.vertical.hybrid_level_parameters(137))
         sp_host = (101325.0 * (1.0 - 0.35 * np.random.default_rng(20260313).random(inner) ** 3)).astype(dt)
         hp = ekm_hip.HybridPressure(Ah, Bh, ekm_hip.to_device(sp_host))
         # t, q drawn around the hybrid-level pressure (materialised once for the generator, then dropped)

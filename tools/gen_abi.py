@@ -250,6 +250,15 @@ EKM_API int ekm_geopotential_on_hybrid_levels_f64(int dev, void* stream, const d
                                                   const double* sp, const double* zs, const double* t, const double* q,
                                                   size_t npts, uint32_t nfull, int top_is_zero, double alpha_top,
                                                   int mode, double* out);
+/* The same bottom-up scan for callers who already hold alpha and delta (outputs of pressure_on_hybrid_levels):
+ * reference vertical/array/vertical.py:741-893 (relative_geopotential_thickness_on_hybrid_levels_from_alpha_delta).
+ * t, q, alpha, delta, out: [nfull, npts] level-major; 16 B read + 4 B written per point (fp32). */
+EKM_API int ekm_geopotential_thickness_from_alpha_delta_f32(int dev, void* stream, const float* t, const float* q,
+                                                            const float* alpha, const float* delta, size_t npts,
+                                                            uint32_t nfull, float* out);
+EKM_API int ekm_geopotential_thickness_from_alpha_delta_f64(int dev, void* stream, const double* t, const double* q,
+                                                            const double* alpha, const double* delta, size_t npts,
+                                                            uint32_t nfull, double* out);
 /* *flag |= any(a0 + b0*sp[i] <= thresh); *flag must be zeroed by the caller (ekm_memset) */
 EKM_API int ekm_any_le_f32(int dev, void* stream, const float* sp, size_t n, float a0, float b0, float thresh,
                            int32_t* flag);

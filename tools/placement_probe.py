@@ -37,8 +37,9 @@ def main():
         chk(lib.ekm_malloc(dev, nbytes, C.byref(p)))
         return p.value
 
-    g = np.load(os.path.join(ROOT, "tests", "golden", "vertical_golden.npz"))
-    A, B = (g[f"coef.137.{k}"].astype(np.float32) for k in "AB")
+    from ekm_hip.vertical import hybrid_level_parameters
+
+    A, B = (x.astype(np.float32) for x in hybrid_level_parameters(137))
     sp = (101325.0 * (1.0 - 0.35 * np.random.default_rng(1).random(INNER) ** 3)).astype(np.float32)
     sets = []
     for s in range(a.sets):

@@ -85,9 +85,10 @@ def main():
     if a.pmode == "hybrid" or "geopotential" in a.workloads:
         import numpy as np
 
-        g = np.load(os.path.join(ROOT, "tests", "golden", "vertical_golden.npz"))
+        from ekm_hip.vertical import hybrid_level_parameters
+
         dt = np.float32 if a.dtype == "f32" else np.float64
-        A, B = (g[f"coef.137.{k}"][137 - a.levels:].astype(dt) for k in "AB")
+        A, B = (x[137 - a.levels:].astype(dt) for x in hybrid_level_parameters(137))
         sp = (101325.0 * (1.0 - 0.35 * np.random.default_rng(1).random(INNER) ** 3)).astype(dt)
         zs = np.maximum(0.0, (101325.0 - sp.astype(np.float64)) / 1.2).astype(dt)
         hyb = []
