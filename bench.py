@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-slab-levels", type=int, default=8,
                     help="levels (1800 x 3600 points each) of the slab the single-core CPU baseline runs on")
+    ap.add_argument("--allow-shared-device", action="store_true",
+                    help="more ranks than visible GPUs: still report a value (ranks share devices, so it is NOT a scaling "
+                         "measurement); without it such a run reports value null and oversubscribed true")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise rendezvous/sharding/reporting without touching a GPU (CI on CPU); value is null")
     ap.add_argument("--tiles", type=int, default=0)
@@ -290,7 +293,7 @@ def main():
 
         lib = _ffi.lib()
         ndev = ekm_hip.device_count()
-        dev = dist.local_rank % ndev
+        dev = dist.local_rank % ndev  # more ranks than devices share them: flagged below, value null unless allowed
         ekm_hip.set_device(dev)
         if args.tiles or args.unroll:
             _ffi.check(lib.ekm_set_tuning(args.tiles, args.unroll))
@@ -408,6 +411,11 @@ def main():
 
     if dist.rank == 0:
         value = None if args.dry_run else n_total * args.steps / elapsed
+        devices = sorted({r["device"] for r in per_rank if r["device"] >= 0})
+        ndev_min = min((r["hip_device_count"] for r in per_rank if r["hip_device_count"] >= 0), default=-1)
+        oversub = not args.dry_run and len(devices) < dist.world
+        if oversub and not args.allow_shared_device:
+            value = None  # ranks shared a GPU: whatever this is, it is not the N-GPU rate
         roof = None
         if kernel_ms:
             achieved = bpp * n_local / (kernel_ms * 1e-3) / 1e9
@@ -420,9 +428,16 @@ def main():
                     "kernel_ms": round(kernel_ms, 4),
                     "kernel_ms_median": round(float(np.median(per_launch)), 4),
                     "kernel_ms_min": round(float(np.min(per_launch)), 4)}
-            if args.workload.startswith("wetbulb"):
-                # honest label: these kernels are limited by VALU issue (transcendentals at 1/4 rate), not by HBM
-                roof["limiter"] = "valu-issue (DESIGN.md section 4); frac is still quoted against the HBM roofline"
+            valu = valu_from_profiles(args)
+            if args.workload.startswith("wetbulb") and valu:
+                # These kernels are bound by VALU issue (transcendentals at a quarter rate), not by HBM: the fraction is
+                # quoted against THAT roof -- executed issue units per point (SQ counters of this same command,
+                # committed) x points / kernel time, against what the VALU microbenchmark sustains on this part.
+                units = valu["units_per_point"] * n_local / (kernel_ms * 1e-3)
+                roof.update(bound="valu", achieved=float(f"{units:.4g}"), peak=valu["peak"], unit="issue-units/s",
+                            frac=round(units / valu["peak"], 4), issue_units_per_point=valu["units_per_point"],
+                            valu_source=valu["source"], hbm_achieved_gbs=round(achieved, 1),
+                            hbm_frac=round(achieved / HBM_PEAK_GBS, 4))
         line = {
             "metric": "grid-points/sec for fused thermo pipeline; achieved HBM GB/s vs peak",
             "value": value, "unit": "grid-points/s", "n_gpus": dist.world, "steps": args.steps,
@@ -435,6 +450,7 @@ def main():
                        "entry_point": f"ekm_{entry}_{args.dtype}", "points_per_gpu": n_total // dist.world, "p_mode": args.pmode,
                        "points_total": n_total, "shard_cut": sh["cut"], "per_rank": per_rank},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+            "hip_device_count": ndev_min, "devices_used": devices, "oversubscribed": oversub,
         }
         if args.dry_run:
             line["dry_run"] = True
@@ -470,10 +486,7 @@ def check_parity(args, t, q, p, plev, outs, sh, nlev, np_dtype, hyb=None):
                 "nan_mismatch": nanmm, "tolerance": "atol 10 m2/s2 + rtol 1e-6 (reference's fp32 bar)" if args.dtype == "f32" else tol,
                 "excluded_regime_boundary_points": 0, "ok": ok}
     wins = []
-    lo_lev = 0
-    if args.pmode == "hybrid" and args.workload != "hybrid_levels":
-        lo_lev = min(36, nlev - 1)  # above ~25 hPa the synthetic humidity is unphysical
-    for lev in np.linspace(lo_lev, nlev - 1, 32).round().astype(int):
+    for lev in np.linspace(0, nlev - 1, 32).round().astype(int):  # the whole column, hybrid top levels (1 Pa ...) included
         lo = int(lev) * ncol + 4321 if by_columns else int(lev) * INNER - first + 4321
         if 0 <= lo and lo + 256 <= n_local:
             wins.append((int(lev), lo))
@@ -492,41 +505,62 @@ def check_parity(args, t, q, p, plev, outs, sh, nlev, np_dtype, hyb=None):
         pl = plev.to_host()
         hp = np.concatenate([np.full(256, pl[lev], np_dtype) for lev, _ in wins])
     want = (hp,) if args.workload == "hybrid_levels" else oracle_call(args.workload, ht, hq, hp)
-    # No point is excluded: the kernels settle Davies-Jones regime ties in double (csrc/thermo_math.hpp::davies_regime)
-    edge = None
-    bis = args.workload == "wetbulb_bisect"
-    noisy = None
-    if bis:  # points where sign() of the reference's own residual is rounding noise are excluded and counted
-        from oracle import conditioning
+    grab = lambda o: np.concatenate([o.flat_slice(lo, lo + 256).to_host() for _, lo in wins])  # noqa: E731
+    if args.workload == "wetbulb_bisect":
+        # the 12-step sign search is quantised to 120/4096 K.  No point is excluded: every differing point must be a NaN
+        # one of the reference's two precisions also has, or lie within 2 quanta of the fp32 / fp64 reference or of a
+        # lattice temperature where the reference's own residual is rounding noise (oracle/census.py::bisect_job)
+        from oracle import census
 
-        noisy = conditioning.bisect_sign_noise("wet_bulb_temperature_from_specific_humidity", [ht, hq, hp], {},
-                                               2e-6 if args.dtype == "f32" else 1e-13)
-    worst, nan_mismatch, worst_abs = 0.0, 0, 0.0
+        b = census.bisect_job(dict(t=ht, q=hq, p=hp, got=grab(outs[0])))[0]
+        return {"points": int(ht.size), "identical": b["identical"], "one_quantum": b["one_quantum"],
+                "two_quanta": b["two_quanta"], "more_than_two_quanta": b["more"], "nan_mismatch": b["nan_mismatch"],
+                "differing_points_unanchored": b["differ_unanchored"], "max_rel_err": b["max_quanta"] * 120.0 / 4096.0 / 250.0,
+                "tolerance": "2 quanta of the 12-step search = 0.0586 K absolute; differing points anchored to the fp32 / fp64 "
+                             "reference or to a noise point of the reference's own residual",
+                "excluded_points": 0, "ok": bool(b["more"] == 0 and b["differ_unanchored"] == 0)}
+    # No point is excluded: the kernels settle Davies-Jones regime ties in double (csrc/thermo_math.hpp::davies_regime)
+    worst, nan_mismatch, explained = 0.0, 0, 0
     for k, (o, w) in enumerate(zip(outs, want)):
-        g = np.concatenate([o.flat_slice(lo, lo + 256).to_host() for _, lo in wins]).astype(np.float64)
+        g = grab(o).astype(np.float64)
         w = np.asarray(w, dtype=np.float64)
-        if edge is not None and k == len(want) - 1:
-            g, w = g[~edge], w[~edge]
-        if noisy is not None:
-            g, w = g[~noisy], w[~noisy]
-        nan_mismatch += int((np.isnan(g) != np.isnan(w)).sum())
+        nanmm = np.isnan(g) != np.isnan(w)
         with np.errstate(all="ignore"):
-            a = np.abs(g - w)
-            r = a / np.abs(w)
-        a, r = a[np.isfinite(a)], r[np.isfinite(r)]
+            r = np.abs(g - w) / np.abs(w)
+        r = np.where(np.isfinite(r), r, 0.0)
+        is_tw = args.workload == "wetbulb" or (args.workload == "full" and k == 5)
+        if is_tw and ((r > tol) | nanmm).any():
+            # hPa-level pressures (hybrid top levels): a miss counts unless the reference's OWN one-step Newton amplifies
+            # input perturbations enough to explain it (oracle/conditioning.py::newton_amplification, fp64 oracle only)
+            from oracle import conditioning
+
+            miss = np.flatnonzero((r > tol) | nanmm)
+            kap = conditioning.newton_amplification(ht[miss], hq[miss], hp[miss])
+            ok = np.isinf(kap) | (~nanmm[miss] & (r[miss] <= 8.0 * kap * 2.0 ** -24))
+            explained += int(ok.sum())
+            r[miss[ok]] = 0.0
+            nanmm[miss[ok]] = False
+        nan_mismatch += int(nanmm.sum())
         worst = max(worst, float(r.max()) if r.size else 0.0)
-        worst_abs = max(worst_abs, float(a.max()) if a.size else 0.0)
-    res = {"points": int(ht.size), "max_rel_err": worst, "nan_mismatch": nan_mismatch, "tolerance": tol,
-           "excluded_regime_boundary_points": int(edge.sum()) if edge is not None else 0,
-           "ok": bool(nan_mismatch == 0 and worst <= tol)}
-    if bis:
-        # the 12-step sign search is quantised to 120/4096 K: a rounding-level change of one residual moves
-        # the answer by at most two quanta (the reference's own tests allow rtol 1e-3 here)
-        quantum = 120.0 / 4096.0
-        res.update(tolerance="2 quanta of the 12-step search = 0.0586 K absolute", max_abs_err=worst_abs,
-                   excluded_sign_noise_points=int(noisy.sum()),
-                   ok=bool(nan_mismatch == 0 and worst_abs <= 2 * quantum * (1 + 1e-6)))
-    return res
+    return {"points": int(ht.size), "max_rel_err": worst, "nan_mismatch": nan_mismatch, "tolerance": tol,
+            "excluded_points": 0, "tw_misses_explained_by_reference_amplification": explained,
+            "levels_sampled": [int(w[0]) for w in wins][:1] + [int(w[0]) for w in wins][-1:],
+            "ok": bool(nan_mismatch == 0 and worst <= tol)}
+
+
+def valu_from_profiles(args):
+    """Executed VALU issue units per point of this workload (SQ_INSTS_VALU + 3 x SQ_INSTS_VALU_TRANS_F32 from a
+    rocprofv3 --pmc pass of this same command, tools/profile_valu.sh) and the issue rate the VALU microbenchmark
+    (tools/microbench/valu_rates.hip) sustains on this part, both committed in profiles/valu_latest.json."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu_latest.json")) as f:
+            d = json.load(f)
+        units = d["units_per_point"].get(f"{args.workload}:{args.pmode}:{args.dtype}")
+        if units is None:
+            return None
+        return {"units_per_point": units, "peak": d["peak_issue_units_per_s"], "source": d["source"]}
+    except Exception:
+        return None
 
 
 def traffic_from_profiles(args, n_local):

@@ -156,7 +156,12 @@ __global__ __launch_bounds__(256) void synth_fill(T* t, T* q, T* p, uint64_t fir
     // q = specific_humidity_from_relative_humidity(t, rh, p), capped (thermo.py:629-663)
     const double e = rh * es_mixed<double>(tv) / 100.0;
     double qv = q_from_e<double>(e, pv, 1e-4);
-    qv = fmin(qv, 0.04);
+    double qcap = 0.04;
+    // around a GIVEN pressure (hybrid model levels, which reach 1 Pa) the cap follows the pressure: the moisture
+    // the real atmosphere holds falls off roughly as p^3 (6e-3 at 500 hPa, 1e-3 at 300 hPa, 4e-5 at 100 hPa) down to
+    // the stratospheric 3e-6 -- a q of 0.04 at 38 Pa is not a state any model level is ever in
+    if (p_given) qcap = fmax(3e-6, 0.04 * (pv / 101325.0) * (pv / 101325.0) * (pv / 101325.0));
+    qv = fmin(qv, qcap);
     if (!(qv == qv)) qv = 3e-6;
     t[i] = (T)tv;
     q[i] = (T)qv;

@@ -13,6 +13,7 @@ from ._ffi import EkmError, EkmLibraryError  # noqa: F401
 from .device import (  # noqa: F401
     DeviceArray,
     current_device,
+    current_stream,
     device_count,
     device_info,
     empty_cache,

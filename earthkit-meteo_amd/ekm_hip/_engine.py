@@ -141,6 +141,13 @@ def run(name, args, ints=(), eps=None, dtype=None):
 
     devs = current_devices()
     numpy_only = not any(isinstance(a, (DeviceArray, HybridPressure)) for a in args)
+    if devs and len(devs) > 1 and not numpy_only:
+        # a DeviceArray lives on ONE GPU: computing on it inside multi_gpu() would silently use that single device
+        where = sorted({a.device for a in args if isinstance(a, DeviceArray)}
+                       | {a.sp.device for a in args if isinstance(a, HybridPressure) and isinstance(a.sp, DeviceArray)})
+        raise _ffi.EkmError(f"{name}: inside ekm_hip.multi_gpu(devices={list(devs)}) the inputs must be host (NumPy) arrays, which "
+                            f"are sharded across the GPUs; these are device-resident on GPU {where} -- call it outside the "
+                            f"block, or shard by hand with ekm_hip.shard_bounds and one DeviceArray per device")
     if numpy_only:
         multi = bool(devs) and len(devs) > 1
         if multi or sum(np.asarray(a).nbytes for a in args if np.ndim(a) > 0) >= _STREAM_BYTES:

@@ -31,36 +31,65 @@ def _ept_and_p(func, inputs, kwargs):
     return ept.ravel().copy(), p.ravel().copy(), m
 
 
-def bisect_sign_noise(func, inputs, kwargs, thresh):
+def bisect_sign_noise(func, inputs, kwargs, thresh, return_points=False):
     """Points whose bisection meets a residual |ept*exp(-G) - th_sat| <= thresh*th_sat on the
     oracle's own fp64 path (e.g. exactly saturated input, where the residual at the second lattice
     point is mathematically zero): ``sign()`` is noise there and one early flip can end in the
-    ``p - es < eps`` NaN region."""
+    ``p - es < eps`` NaN region.  With `return_points` also the lattice temperatures at which that
+    happens, shape (n, 12), NaN where the step is decided cleanly: a search whose sign flips at such
+    a point ends within one quantum of it (it converges back onto it from the other side)."""
     with np.errstate(all="ignore"):
         ept, p, m = _ept_and_p(func, inputs, kwargs)
         meth = orc._EPT[m]
         t = np.full(ept.size, orc.T0 - 20.0)
         dt = 120.0
         noisy = np.zeros(ept.size, dtype=bool)
-        for _ in range(12):
+        pts = np.full((ept.size, 12), np.nan) if return_points else None
+        for it in range(12):
             st = orc._state(t=t, p=p)
             dt /= 2.0
             g = meth["gsat"](st, scale=-1.0)
             th = meth["thsat"](st)
             r = ept * np.exp(g) - th
-            noisy |= np.abs(r) <= thresh * np.abs(th)
+            here = np.abs(r) <= thresh * np.abs(th)
+            noisy |= here
+            if return_points:
+                pts[here, it] = t[here]
             t = t + np.sign(r) * dt
-    return noisy
+    return (noisy, pts) if return_points else noisy
 
 
 def newton_regime_boundary(func, inputs, kwargs, thresh):
-    """Points whose c_te lies within relative `thresh` of a regime threshold (D(p), 1, 0.4)."""
+    """Points whose c_te lies within relative `thresh` of a regime threshold (D(p), 1, 0.4); a tuple of
+    thresholds gives a tuple of masks (c_te is formed once)."""
     with np.errstate(all="ignore"):
         ept, p, _ = _ept_and_p(func, inputs, kwargs)
         pp = np.power(p / orc.p0, orc.kappa)
         c_te = np.power(273.16 / (ept * pp), orc.LAMBDA)
         d = 1.0 / (0.1859e-5 * p + 0.6512)
-        near = np.abs(c_te - d) <= thresh * d
-        near |= np.abs(c_te - 1.0) <= thresh
-        near |= np.abs(c_te - 0.4) <= thresh * 0.4
-    return near
+        dist = np.minimum(np.minimum(np.abs(c_te - d) / d, np.abs(c_te - 1.0)), np.abs(c_te - 0.4) / 0.4)
+        if isinstance(thresh, (tuple, list)):
+            return tuple(dist <= th for th in thresh)
+        return dist <= thresh
+
+
+def newton_amplification(t, q, p, h=1e-6):
+    """How strongly the reference's own one-step Newton wet-bulb (ifs) amplifies a relative perturbation of its
+    inputs, on the fp64 oracle: kappa = max over (t, q, p) of |tw(x(1+h)) - tw(x(1-h))| / (2 h |tw(x)|); inf where a
+    perturbed evaluation changes NaN-ness (the point sits on the edge of the p - es < eps / tw <= 0 NaN regions or on
+    a regime threshold).  At hPa-level pressures (p < ~60 Pa: es(tw) ~ p, qs ~ 1) the single Newton step is far
+    from converged and kappa reaches 1e3-1e6: an fp32 rounding of an intermediate (6e-8) then shows up at 1e-4 and
+    beyond in ANY fp32 evaluation, the reference's own included.  Identified from the oracle alone."""
+    with np.errstate(all="ignore"):
+        x = [np.asarray(a, dtype=np.float64) for a in (t, q, p)]
+        base = orc.wet_bulb_temperature_from_specific_humidity(*x, "ifs", "newton")
+        kappa = np.zeros(base.shape)
+        for i in range(3):
+            lo, hi = list(x), list(x)
+            lo[i], hi[i] = x[i] * (1.0 - h), x[i] * (1.0 + h)
+            a = orc.wet_bulb_temperature_from_specific_humidity(*lo, "ifs", "newton")
+            b = orc.wet_bulb_temperature_from_specific_humidity(*hi, "ifs", "newton")
+            k = np.abs(b - a) / (2.0 * h * np.abs(base))
+            k = np.where(np.isnan(a) | np.isnan(b) | np.isnan(base), np.inf, k)
+            kappa = np.maximum(kappa, k)
+    return kappa

@@ -30,9 +30,13 @@ def ek():
 def pytest_terminal_summary(terminalreporter):
     """Print how much of every parity relaxation was actually used (tests/_compare.py)."""
     try:
-        from _compare import LEDGER
+        from _compare import CENSUS, LEDGER
     except Exception:
         return
+    if CENSUS:
+        terminalreporter.write_sep("-", "whole-field parity censuses (tests/test_gpu_census.py)")
+        for line in CENSUS:
+            terminalreporter.write_line(line)
     if not LEDGER:
         return
     agg = {}

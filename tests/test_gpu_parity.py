@@ -40,16 +40,19 @@ def test_golden_vectors(ek, case):
         want_dtype = np.float32 if case["dtype"] == "f32" else np.float64
         assert o.dtype == want_dtype, (case["id"], o.dtype)  # dtype-preserving (fp32 in -> fp32 out)
         both = [golden()[".".join([cid[0], tag] + cid[2:]) + f".out{i}"] for tag in ("f32", "f64")]
-        unstable = ref64 = None
+        unstable = ref64 = noise_t = None
         if bisect:
-            unstable = bisect_unstable(*both) | bisect_sign_noise(
-                orc_, case["func"], case_inputs(case), case["kwargs"], 3e-6 if case["dtype"] == "f32" else 1e-14)
+            noisy, noise_t = bisect_sign_noise(orc_, case["func"], case_inputs(case), case["kwargs"],
+                                               3e-6 if case["dtype"] == "f32" else 1e-14, return_points=True)
+            unstable = bisect_unstable(*both) | noisy
+            if case["dtype"] == "f32":
+                ref64 = both[1]  # unstable points may sit with the fp64 reference (NaN-ness, 2 quanta)
         elif "newton" in case["id"]:
             unstable = newton_regime_boundary(case["func"], case_inputs(case), case["kwargs"],
                                               1e-5 if case["dtype"] == "f32" else 1e-13)
             if case["dtype"] == "f32":
                 ref64 = both[1]  # the reference's own fp64 answer: conditioning yardstick for the Newton step
-        assert_parity(o, g, case["dtype"], case["id"], bisect=bisect, unstable=unstable, ref64=ref64)
+        assert_parity(o, g, case["dtype"], case["id"], bisect=bisect, unstable=unstable, ref64=ref64, noise_t=noise_t)
 
 
 # ---- (2) the reference's inline known-answer vectors ----
@@ -205,12 +208,13 @@ def test_every_function_on_synthetic_columns(ek, orc, pool, tag, func, args, kwa
     want = _outs(getattr(orc, func)(*[a.copy() for a in ins], **kwargs))
     tm = kwargs.get("t_method")
     for k, (g_, w_) in enumerate(zip(got, want)):
-        unstable = ref64 = None
+        unstable = ref64 = noise_t = None
         if tm == "bisect":
-            unstable = bisect_sign_noise(orc, func, ins, kwargs, 3e-6 if tag == "f32" else 1e-14)
+            unstable, noise_t = bisect_sign_noise(orc, func, ins, kwargs, 3e-6 if tag == "f32" else 1e-14, return_points=True)
             if tag == "f32":
                 w64 = _outs(getattr(orc, func)(*[a.astype(np.float64) for a in ins], **kwargs))[k]
                 unstable |= bisect_unstable(w_, w64)
+                ref64 = w64
         elif tm == "newton":
             unstable = newton_regime_boundary(func, ins, kwargs, 1e-5 if tag == "f32" else 1e-13)
             if tag == "f32":
@@ -227,7 +231,7 @@ def test_every_function_on_synthetic_columns(ek, orc, pool, tag, func, args, kwa
             ref64 = ref64[keep] if ref64 is not None else None
             unstable, allowed = None, 0.01 * g_.size
         assert_parity(g_, w_, tag, f"{func} {kwargs} {tag}", bisect=tm == "bisect", unstable=unstable, ref64=ref64,
-                      max_relaxed=allowed)
+                      max_relaxed=allowed, noise_t=noise_t)
 
 
 @pytest.mark.parametrize("tag", ["f32", "f64"])
@@ -240,11 +244,12 @@ def test_synthetic_bisect_vs_oracle(ek, orc, slab, tag, method):
     d64 = {k: v.astype(np.float64) for k, v in d32.items()} if tag == "f32" else d
     ref32 = orc.wet_bulb_temperature_from_specific_humidity(d32["t"], d32["q"], d32["p"], ept_method=method)
     ref64 = orc.wet_bulb_temperature_from_specific_humidity(d64["t"], d64["q"], d64["p"], ept_method=method)
-    unstable = bisect_sign_noise(orc, "wet_bulb_temperature_from_specific_humidity", [d["t"], d["q"], d["p"]],
-                                 {"ept_method": method}, 3e-6 if tag == "f32" else 1e-14)
+    unstable, noise_t = bisect_sign_noise(orc, "wet_bulb_temperature_from_specific_humidity", [d["t"], d["q"], d["p"]],
+                                          {"ept_method": method}, 3e-6 if tag == "f32" else 1e-14, return_points=True)
     if tag == "f32":
         unstable |= bisect_unstable(ref32, ref64)
-    assert_parity(got, want, tag, f"bisect {method} {tag}", bisect=True, unstable=unstable)
+    assert_parity(got, want, tag, f"bisect {method} {tag}", bisect=True, unstable=unstable,
+                  ref64=ref64 if tag == "f32" else None, noise_t=noise_t)
     # the search lands on the same 120/4096 K lattice as the reference
     k = (got.astype(np.float64) - (273.16 - 20)) / BISECT_QUANTUM
     assert np.allclose(k, np.round(k), atol=2e-3 if tag == "f32" else 1e-9)
@@ -434,6 +439,12 @@ def test_multi_gpu_sharding_in_process(ek, orc, slab):
     assert few.shape == (2, t.shape[1])
     with pytest.raises(ek.EkmError):
         ek.multi_gpu([0, 99])
+    # device-resident inputs live on ONE GPU: inside multi_gpu() that is an error, not a silent single-device run
+    dt, dp = ek.to_device(t), ek.to_device(p)
+    with ek.multi_gpu([0, 0]):
+        with pytest.raises(ek.EkmError, match="inside ekm_hip.multi_gpu"):
+            ek.thermo.potential_temperature(dt, dp)
+    assert isinstance(ek.thermo.potential_temperature(dt, dp), ek.DeviceArray)  # fine outside the block
 
 
 def test_more_than_2_to_32_points(ek, orc):

@@ -210,12 +210,21 @@ def test_bench_two_ranks_strong_scaling_on_one_device(ek):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
            "--levels", "16", "--pmode", "level"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    if ek.device_count() < 2:
+        # more ranks than GPUs without --allow-shared-device: the line says so and carries no value
+        r = subprocess.run(cmd[:-4] + ["--levels", "4", "--pmode", "level"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert d["oversubscribed"] is True and d["value"] is None and d["hip_device_count"] == 1 and d["devices_used"] == [0]
+        cmd.append("--allow-shared-device")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(line) == 1
     d = json.loads(line[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["oversubscribed"] == (ek.device_count() < 2) and d["hip_device_count"] == ek.device_count()
     assert d["parity"]["ok"] and d["parity"]["nan_mismatch"] == 0
     ranks = d["config"]["per_rank"]
     assert [x["points"] for x in ranks] == [8 * 1800 * 3600] * 2 and all(x["kernel_ms"] > 0 for x in ranks)

@@ -24,13 +24,16 @@ def test_kernel_math_vs_reference(case):
     cid = case["id"].split(".")
     for i, (o, g) in enumerate(zip(outs, case_outputs(case))):
         both = [golden()[".".join([cid[0], tag] + cid[2:]) + f".out{i}"] for tag in ("f32", "f64")]
-        unstable = ref64 = None
+        unstable = ref64 = noise_t = None
         if bisect:
-            unstable = bisect_unstable(*both) | bisect_sign_noise(
-                orc, case["func"], case_inputs(case), case["kwargs"], 3e-6 if case["dtype"] == "f32" else 1e-14)
+            noisy, noise_t = bisect_sign_noise(orc, case["func"], case_inputs(case), case["kwargs"],
+                                               3e-6 if case["dtype"] == "f32" else 1e-14, return_points=True)
+            unstable = bisect_unstable(*both) | noisy
+            if case["dtype"] == "f32":
+                ref64 = both[1]  # unstable points may sit with the fp64 reference (NaN-ness, 2 quanta)
         elif "newton" in case["id"]:
             unstable = newton_regime_boundary(case["func"], case_inputs(case), case["kwargs"],
                                               1e-5 if case["dtype"] == "f32" else 1e-13)
             if case["dtype"] == "f32":
                 ref64 = both[1]  # the reference's own fp64 answer: conditioning yardstick for the Newton step
-        assert_parity(o, g, case["dtype"], case["id"], bisect=bisect, unstable=unstable, ref64=ref64)
+        assert_parity(o, g, case["dtype"], case["id"], bisect=bisect, unstable=unstable, ref64=ref64, noise_t=noise_t)
