@@ -225,8 +225,7 @@ def relative_geopotential_thickness_on_hybrid_levels_from_alpha_delta(t, q, alph
     """Geopotential thickness between the surface and the hybrid full levels from alpha and delta the caller
     already holds (outputs of `pressure_on_hybrid_levels`): vertical.py:741-893.  The same bottom-up column scan
     as `relative_geopotential_thickness_on_hybrid_levels`, with alpha and delta STREAMED (16 B read + 4 B written
-    per point in fp32) instead of formed from A, B, sp.  Result dtype = NumPy promotion of the four inputs (the
-    reference hands out fp64 alpha / delta whatever the input dtype, so fp32 t, q with those give fp64)."""
+    per point in fp32) instead of formed from A, B, sp.  NumPy result dtype = that of t and q, as in the reference."""
     arrs = dict(t=t, q=q, alpha=alpha, delta=delta)
     on_device = any(isinstance(v, DeviceArray) for v in arrs.values())
     if on_device and vertical_axis != 0:
@@ -234,10 +233,13 @@ def relative_geopotential_thickness_on_hybrid_levels_from_alpha_delta(t, q, alph
     host = {k: (v if isinstance(v, DeviceArray) else np.asarray(v)) for k, v in arrs.items()}
     if vertical_axis != 0:
         host = {k: np.moveaxis(v, vertical_axis, 0) for k, v in host.items()}
-    out_dtype = np.result_type(*[v.dtype for v in host.values()])
+    # the reference writes into zeros_like(R(q) * t) (vertical.py:762): the RESULT has the dtype of t and q, while the
+    # arithmetic runs in the promotion of all four (its own alpha / delta are fp64 whatever the input dtype)
+    out_dtype = np.result_type(host["t"].dtype, host["q"].dtype)
     if out_dtype.kind != "f":
         out_dtype = _F64
-    dtype = _F32 if out_dtype in (_F32, np.dtype(np.float16)) else _F64
+    cd = np.result_type(*[v.dtype for v in host.values()])
+    dtype = _F32 if cd in (_F32, np.dtype(np.float16)) else _F64
     shape = tuple(host["t"].shape)
     if len(shape) == 0 or any(tuple(v.shape) != shape for v in host.values()):
         raise ValueError("t, q, alpha and delta must have the same shape [levels, ...]: "
@@ -256,7 +258,7 @@ def relative_geopotential_thickness_on_hybrid_levels_from_alpha_delta(t, q, alph
     _ffi.check(getattr(lib, f"ekm_geopotential_thickness_from_alpha_delta_{tag}")(
         device, stream, d["t"].ptr, d["q"].ptr, d["alpha"].ptr, d["delta"].ptr, npts, nlev, out.on(stream)))
     if on_device:
-        return out
+        return out  # device-resident: in the arithmetic dtype
     res = out.to_host().astype(out_dtype, copy=False)
     out.free()
     if vertical_axis != 0:

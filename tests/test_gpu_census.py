@@ -182,15 +182,18 @@ def test_census_p5_hybrid_levels_all_137_levels(ek, tq):
     _report("census P5 fp32, hybrid levels formed in-kernel, 137 levels (1 Pa ... surface)", total, N3, time.time() - t0,
             extra=(f"; tw: levels with a miss {hit[:1]}..{hit[-1:]} (p <= {max([p_mid[k] for k in hit], default=0):.0f} Pa), "
                    f"misses explained by the reference's own amplification {e['over_explained_by_amplification']}, "
+                   f"regime ties flipped by the fp32 reference's own rounding (ours = the fp64 reference) "
+                   f"{e['over_regime_flip_of_the_fp32_reference']} of {e['band_1e5']} boundary points, "
                    f"unexplained {e['over_unexplained']}; the reference's fp32 vs its fp64 beyond 1e-4: "
                    f"{e['reference_fp32_vs_fp64_over']} (NaN {e['reference_fp32_vs_fp64_nan_mismatch']})"))
     _strict(total[:5], NAMES5[:5])
     assert e["over_unexplained"] == 0, e
+    assert e["over_regime_flip_of_the_fp32_reference"] <= 0.02 * e["band_1e5"], e  # tests/_compare.py BOUNDARY_VIOLATION_FRACTION
     assert e["over"] <= 2 * e["reference_fp32_vs_fp64_over"] + 4, e
     assert e["nan_mismatch"] <= 2 * e["reference_fp32_vs_fp64_nan_mismatch"] + 4, e
-    for k in range(NLEV):  # from 100 Pa down to the surface nothing at all may miss
+    for k in range(NLEV):  # from 100 Pa down to the surface nothing may miss but a regime tie the fp32 reference flipped
         if p_mid[k] >= 100.0:
-            assert per[k][5]["over"] == 0 and per[k][5]["nan_mismatch"] == 0, (k, per[k][5])
+            assert per[k][5]["over"] == per[k][5]["over_regime_flip_of_the_fp32_reference"] and per[k][5]["nan_mismatch"] == 0, (k, per[k][5])
     assert min(hit, default=0) <= 9 or not hit  # level 9 (38 Pa) was looked at, not skipped
     for a in outs + [d_sp, d_a, d_b]:
         a.free()

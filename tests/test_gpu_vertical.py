@@ -163,8 +163,8 @@ def test_thickness_from_alpha_delta(ek, dt):
     al, de = G[f"chain.{dt}.alpha"], G[f"chain.{dt}.delta"]
     got = F(t, q, al, de)
     w = G[f"chain.{dt}.from_alpha_delta"]
-    assert got.dtype == w.dtype == np.float64 and got.shape == w.shape  # fp64 alpha / delta promote the result
-    assert np.allclose(got, w, rtol=1e-6, atol=1e-9), np.abs(got - w).max()
+    assert got.dtype == w.dtype == npdt and got.shape == w.shape  # the result has the dtype of t and q (vertical.py:762)
+    assert np.allclose(got, w, rtol=1e-6, atol=1e-9), np.abs(got - w).max()  # the arithmetic ran in fp64 (alpha, delta)
     # the same through the fused producer (A, B, sp): identical up to the fp64 bar
     if dt == "f64":
         fused = ek.vertical.relative_geopotential_thickness_on_hybrid_levels(t, q, G["coef.137.A"], G["coef.137.B"],
@@ -186,7 +186,7 @@ def test_thickness_from_alpha_delta(ek, dt):
         # vertical axis last (square-free shape): moved to the front and back
         tt = np.ascontiguousarray(np.moveaxis(t, 0, -1))
         moved = F(tt, np.moveaxis(q, 0, -1), np.moveaxis(al, 0, -1), np.moveaxis(de, 0, -1), vertical_axis=1)
-        assert moved.shape == tt.shape and np.allclose(np.moveaxis(moved, -1, 0), got, rtol=1e-12, atol=0)
+        assert moved.shape == tt.shape and np.array_equal(np.moveaxis(moved, -1, 0), got)
     with pytest.raises(ValueError, match="same shape"):
         F(t, q[:5], al, de)
 
