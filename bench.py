@@ -42,6 +42,8 @@ WORKLOADS = {
     "p3": ("pipeline_svp_td_rh", 3, 3, 24, "fused es+td+rh"),
     "wetbulb": ("wet_bulb_temperature_from_specific_humidity", 3, 1, 16, "wet-bulb (ifs, newton)"),
     "wetbulb_bisect": ("wet_bulb_temperature_from_specific_humidity", 3, 1, 16, "wet-bulb (ifs, bisect)"),
+    "wetbulb_bisect_bolton35": ("wet_bulb_temperature_from_specific_humidity", 3, 1, 16, "wet-bulb (bolton35, bisect)"),
+    "wetbulb_bisect_bolton39": ("wet_bulb_temperature_from_specific_humidity", 3, 1, 16, "wet-bulb (bolton39, bisect)"),
     "rh": ("relative_humidity_from_specific_humidity", 3, 1, 16, "rh from q"),
     "theta": ("potential_temperature", 2, 1, 12, "potential temperature"),
     "svp": ("saturation_vapour_pressure", 1, 1, 8, "saturation vapour pressure (mixed)"),
@@ -93,6 +95,8 @@ def oracle_call(workload, t, q, p):
             return (orc.wet_bulb_temperature_from_specific_humidity(t, q, p, "ifs", "newton"),)
         if workload == "wetbulb_bisect":
             return (orc.wet_bulb_temperature_from_specific_humidity(t, q, p, "ifs", "bisect"),)
+        if workload.startswith("wetbulb_bisect_"):
+            return (orc.wet_bulb_temperature_from_specific_humidity(t, q, p, workload.rsplit("_", 1)[1], "bisect"),)
         if workload == "rh":
             return (orc.relative_humidity_from_specific_humidity(t, q, p),)
         if workload == "theta":
@@ -352,7 +356,7 @@ def main():
                     "ept_from_specific_humidity": (op_t, op_q, op_p),
                     "potential_temperature": (op_t, op_p), "saturation_vapour_pressure": (op_t,),
                     "pressure_on_hybrid_levels": (), "geopotential_on_hybrid_levels": ()}[entry]
-        ints = {"wetbulb": (0, 1), "wetbulb_bisect": (0, 0), "svp": (0,), "ept": (0,)}.get(args.workload, ())
+        ints = {"wetbulb": (0, 1), "wetbulb_bisect": (0, 0), "wetbulb_bisect_bolton35": (1, 0), "wetbulb_bisect_bolton39": (2, 0), "svp": (0,), "ept": (0,)}.get(args.workload, ())
         cargs = [dev, None] + [C.byref(o) for o in operands] + list(ints) + [o.ptr for o in outs] + [n_local]
         if args.workload == "geopotential":
             zs_host = np.maximum(0.0, (101325.0 - hyb["sph"].astype(np.float64)) / 1.2).astype(np_dtype)  # g*z ~ dp / rho
@@ -506,13 +510,14 @@ def check_parity(args, t, q, p, plev, outs, sh, nlev, np_dtype, hyb=None):
         hp = np.concatenate([np.full(256, pl[lev], np_dtype) for lev, _ in wins])
     want = (hp,) if args.workload == "hybrid_levels" else oracle_call(args.workload, ht, hq, hp)
     grab = lambda o: np.concatenate([o.flat_slice(lo, lo + 256).to_host() for _, lo in wins])  # noqa: E731
-    if args.workload == "wetbulb_bisect":
+    if args.workload.startswith("wetbulb_bisect"):
         # the 12-step sign search is quantised to 120/4096 K.  No point is excluded: every differing point must be a NaN
         # one of the reference's two precisions also has, or lie within 2 quanta of the fp32 / fp64 reference or of a
         # lattice temperature where the reference's own residual is rounding noise (oracle/census.py::bisect_job)
         from oracle import census
 
-        b = census.bisect_job(dict(t=ht, q=hq, p=hp, got=grab(outs[0])))[0]
+        method = args.workload.rsplit("_", 1)[1] if args.workload.count("_") > 1 else "ifs"
+        b = census.bisect_job(dict(t=ht, q=hq, p=hp, got=grab(outs[0]), method=method))[0]
         return {"points": int(ht.size), "identical": b["identical"], "one_quantum": b["one_quantum"],
                 "two_quanta": b["two_quanta"], "more_than_two_quanta": b["more"], "nan_mismatch": b["nan_mismatch"],
                 "differing_points_unanchored": b["differ_unanchored"], "max_rel_err": b["max_quanta"] * 120.0 / 4096.0 / 250.0,

@@ -5,15 +5,35 @@
 // a GPU.  The product (ekm_hip) never loads this library and has no CPU path.
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 #include "ops.hpp"
 
+// Ops that keep a per-workgroup LDS table on the device (ops.hpp::OpTable, the bisection lattice) take the SAME path
+// here -- table filled once, OpTable<Op>::apply per point -- so the table arithmetic the kernels run is what the golden
+// vectors check.  EKM_TWIN_TABLE_FREE=1 selects Op::apply, the table-free statement of the same search.
 template <class Op, class T>
 static int host_map(const T* const* ins, T* const* outs, size_t n, double rp) {
+  std::vector<T> tab;
+  if constexpr (ekm::OpTable<Op>::elems > 0) {
+    const char* env = std::getenv("EKM_TWIN_TABLE_FREE");
+    if (!(env && env[0] == '1')) {
+      tab.resize(ekm::OpTable<Op>::template count<T>());
+      ekm::OpTable<Op>::template fill<T>(tab.data(), 0, 1);
+    }
+  }
   for (size_t i = 0; i < n; ++i) {
     T x[Op::NIN], y[Op::NOUT];
     for (int k = 0; k < Op::NIN; ++k) x[k] = ins[k][i];
-    Op::template apply<T>(x, y, T(rp));
+    if constexpr (ekm::OpTable<Op>::elems > 0) {
+      if (!tab.empty())
+        ekm::OpTable<Op>::template apply<T>(x, y, T(rp), tab.data());
+      else
+        Op::template apply<T>(x, y, T(rp));
+    } else {
+      Op::template apply<T>(x, y, T(rp));
+    }
     for (int k = 0; k < Op::NOUT; ++k) outs[k][i] = y[k];
   }
   return 0;

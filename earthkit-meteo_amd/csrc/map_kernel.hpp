@@ -127,7 +127,7 @@ __device__ __forceinline__ void apply_points(const T (&x)[V][Op::NIN], T (&y)[V]
 }
 
 #define EKM_OP_TABLE(Op, T, name)                                              \
-  __shared__ T name[OpTable<Op>::elems > 0 ? OpTable<Op>::elems : 1];          \
+  __shared__ T name[OpTable<Op>::elems > 0 ? OpTable<Op>::template count<T>() : 1]; \
   if constexpr (OpTable<Op>::elems > 0) {                                      \
     OpTable<Op>::template fill<T>(name, (int)threadIdx.x, kThreads);           \
     __syncthreads();                                                           \
@@ -563,7 +563,7 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
   }
   a.vec_ok = aligned ? 1 : 0;
   // the op's own per-workgroup table (static LDS, OpTable) shares the 64 KiB with the staged level vectors
-  constexpr size_t kTableBytes = (size_t)OpTable<Op>::elems * sizeof(T);
+  constexpr size_t kTableBytes = (size_t)OpTable<Op>::template count<T>() * sizeof(T);
   if ((size_t)lds_elems * sizeof(T) + kTableBytes > kMaxLdsBytes)
     return set_error(EKM_ERR_ARG, "level vectors need %zu B of LDS (max %zu beside this op's %zu-B table)",
                      (size_t)lds_elems * sizeof(T), (size_t)kMaxLdsBytes - kTableBytes, kTableBytes);

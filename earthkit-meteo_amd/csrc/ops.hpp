@@ -137,11 +137,11 @@ struct OpWetBulbFromQ<EPT_IFS, T_NEWTON> {
     const T td = t_from_es(e_from_q(q, p));
     const T tl = lcl_t<LCL_DAVIES>(t, td);
     const T xe = T(k::K0_ifs * k::LOG2E) * q * m_rcp(tl);  // log2 of exp(K0*q/t_lcl)
-    const T te = t * m_exp2(xe);
-    const T lte = m_log2(t * T(1.0 / 273.16)) + xe;        // log2(te/273.16) without waiting for te
-    const T pp = m_exp2(T(k::kappa) * m_log2(p * T(1.0 / k::p0)));
+    const T lte = m_log2(t * T(1.0 / 273.16)) + xe;        // log2(te/273.16) without forming te
     const TeFromTQP<T> exact{t, q, p};
-    y[0] = t_on_ma_newton_ifs_core(te, te, lte, p, pp, T(0.1859e-5) * p + T(0.6512), exact, tie);
+    y[0] = t_on_ma_newton_ifs_core(
+        lte, p, T(0.1859e-5) * p + T(0.6512), [&] { return t * m_exp2(xe); },
+        [&] { return m_exp2(T(k::kappa) * m_log2(p * T(1.0 / k::p0))); }, exact, tie);
   }
 };
 
@@ -166,46 +166,82 @@ struct OpUsesTie<OpWetBulbFromQ<M, T_NEWTON>> {
 };
 
 // ---- ops that keep a per-workgroup table in LDS -------------------------------------------------------
-// OpTable<Op>::elems > 0: the map kernels reserve `elems` values of LDS, call fill() once per workgroup
+// OpTable<Op>::elems > 0: the map kernels reserve count<T>() values of LDS, call fill() once per workgroup
 // (all threads, followed by a barrier) and then OpTable<Op>::apply(x, y, rp, table) instead of Op::apply.
 // Op::apply itself stays the table-free statement of the same arithmetic (host twin, reference for tests).
 template <class Op>
 struct OpTable {
   static constexpr int elems = 0;
+  template <class T>
+  static constexpr int count() {
+    return 0;
+  }
 };
 
-// IFS bisection (the reference's DEFAULT t_method): es_mixed on the 4096-point search lattice
-struct BisectIfsTable {
+// Bisection (the reference's DEFAULT t_method): the saturated parcel on the 4096-point search lattice
+// (thermo_math.hpp::BisectEntry: fp32 pairs (es_m, a_m), fp64 es_m alone; 32 KiB either way).
+template <int METHOD>
+struct BisectTable {
   static constexpr int elems = kBisectLattice;
   template <class T>
+  static constexpr int count() {
+    return kBisectLattice * BisectEntry<METHOD, T>::width;
+  }
+  template <class T>
   EKM_HD static void fill(T* __restrict__ tab, int tid, int nthreads) {
-    for (int m = tid; m < kBisectLattice; m += nthreads) tab[m] = es_mixed(bisect_lattice_t<T>(m));
+    for (int m = tid; m < kBisectLattice; m += nthreads) BisectEntry<METHOD, T>::fill(tab, m);
+  }
+};
+typedef BisectTable<EPT_IFS> BisectIfsTable;
+// bolton35 / bolton39: theta_e as the reference forms it, then the table search
+template <int M>
+struct OpTable<OpTOnMa<M, T_BISECT>> : BisectTable<M> {
+  template <class T>
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
+    y[0] = t_on_ma_bisect_tab<M>(x[0], x[1], tab);
+  }
+};
+template <int M>
+struct OpTable<OpWetBulbFromTd<M, T_BISECT>> : BisectTable<M> {
+  template <class T>
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
+    y[0] = t_on_ma_bisect_tab<M>(ept<M, false>(x[0], x[1], x[2]), x[2], tab);
+  }
+};
+template <int M>
+struct OpTable<OpWetBulbFromQ<M, T_BISECT>> : BisectTable<M> {
+  template <class T>
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
+    y[0] = t_on_ma_bisect_tab<M>(ept<M, true>(x[0], x[1], x[2]), x[2], tab);
   }
 };
 template <>
 struct OpTable<OpTOnMa<EPT_IFS, T_BISECT>> : BisectIfsTable {
   template <class T>
   EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
-    y[0] = t_on_ma_bisect_ifs_tab(x[0], x[1], tab);
+    y[0] = t_on_ma_bisect_ifs_tab(x[0] * m_exp2(T(k::kappa) * m_log2(x[1] * T(1.0 / k::p0))), x[1], tab);
   }
 };
 template <>
 struct OpTable<OpWetBulbFromTd<EPT_IFS, T_BISECT>> : BisectIfsTable {
   template <class T>
   EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
-    y[0] = t_on_ma_bisect_ifs_tab(ept<EPT_IFS, false>(x[0], x[1], x[2]), x[2], tab);
+    // theta_e*(p/p0)^kappa with the two pressure powers cancelled (thermo.py:1169-1175): t*exp(K0*q/t_lcl)
+    const T t = x[0], td = x[1], p = x[2];
+    const T q = q_from_e(es_water(td), p, T(k::eps_default));
+    const T tl = lcl_t<LCL_DAVIES>(t, td);
+    y[0] = t_on_ma_bisect_ifs_tab(t * m_exp2(T(k::K0_ifs * k::LOG2E) * q * m_rcp(tl)), p, tab);
   }
 };
 template <>
 struct OpTable<OpWetBulbFromQ<EPT_IFS, T_BISECT>> : BisectIfsTable {
   template <class T>
   EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
-    // theta_e (thermo.py:1169-1175) and the search share (p0/p)^kappa
+    // the search only needs te = theta_e*(p/p0)^kappa, in which the pressure powers of theta_e (thermo.py:1169-1175)
+    // cancel: te = t*exp(K0*q/t_lcl) -- no log2 / exp2 of the pressure at all
     const T t = x[0], q = x[1], p = x[2];
-    const T thf = m_exp2(T(-k::kappa) * m_log2(p * T(1.0 / k::p0)));
     const T tl = lcl_t<LCL_DAVIES>(t, t_from_es(e_from_q(q, p)));
-    const T the = t * thf * m_exp2(T(k::K0_ifs * k::LOG2E) * q * m_rcp(tl));
-    y[0] = t_on_ma_bisect_ifs_tab(the, p, thf, tab);
+    y[0] = t_on_ma_bisect_ifs_tab(t * m_exp2(T(k::K0_ifs * k::LOG2E) * q * m_rcp(tl)), p, tab);
   }
 };
 
@@ -217,11 +253,25 @@ EKM_HD T wbpt_from_ept(T e, Tie& tie) {
 }
 EKM_OP_T2(OpWbptFromTd, METHOD, TM, 3, 1, y[0] = wbpt_from_ept<METHOD, TM>(ept<METHOD, false>(x[0], x[1], x[2]), tie);)
 EKM_OP_T2(OpWbptFromQ, METHOD, TM, 3, 1, y[0] = wbpt_from_ept<METHOD, TM>(ept<METHOD, true>(x[0], x[1], x[2]), tie);)
+template <int M>
+struct OpTable<OpWbptFromTd<M, T_BISECT>> : BisectTable<M> {
+  template <class T>
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
+    y[0] = t_on_ma_bisect_tab<M>(ept<M, false>(x[0], x[1], x[2]), T(k::p0), tab);
+  }
+};
+template <int M>
+struct OpTable<OpWbptFromQ<M, T_BISECT>> : BisectTable<M> {
+  template <class T>
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
+    y[0] = t_on_ma_bisect_tab<M>(ept<M, true>(x[0], x[1], x[2]), T(k::p0), tab);
+  }
+};
 template <>
 struct OpTable<OpWbptFromTd<EPT_IFS, T_BISECT>> : BisectIfsTable {
   template <class T>
   EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
-    y[0] = t_on_ma_bisect_ifs_tab(ept<EPT_IFS, false>(x[0], x[1], x[2]), T(k::p0), tab);
+    y[0] = t_on_ma_bisect_ifs_tab(ept<EPT_IFS, false>(x[0], x[1], x[2]), T(k::p0), tab);  // (p/p0)^kappa = 1 at p0
   }
 };
 template <>
@@ -280,11 +330,12 @@ struct OpPipelineFull {
     y[3] = td;
     y[4] = the;
 #ifdef EKM_P5_NOWB  // diagnostic build: how long do the nine streams take with the wet-bulb arithmetic removed?
-    y[5] = the + P.pp;
+    y[5] = the + P.l;
 #else
     // thermo.py:1081-1159; te = theta_e*(p/p0)^kappa = t*exp(K0*q/t_lcl): the pressure powers cancel
     const TeFromTQP<T> exact{t, q, p};
-    y[5] = t_on_ma_newton_ifs_core(the, t * ex, m_log2(t * T(1.0 / 273.16)) + xe, p, P.pp, P.dinv, exact, tie);
+    y[5] = t_on_ma_newton_ifs_core(m_log2(t * T(1.0 / 273.16)) + xe, p, P.dinv, [&] { return t * ex; },
+                                   [&] { return m_exp2(T(k::kappa) * P.l); }, exact, tie);
 #endif
   }
 };

@@ -228,6 +228,10 @@ EKM_HD double m_min3abs(double a, double b, double c) {
   return __builtin_fmin(__builtin_fmin(__builtin_fabs(a), __builtin_fabs(b)), __builtin_fabs(c));
 }
 
+// max of two values neither of which is NaN (one v_max_f32 on the device)
+EKM_HD float m_max(float a, float b) { return __builtin_fmaxf(a, b); }
+EKM_HD double m_max(double a, double b) { return __builtin_fmax(a, b); }
+
 // numpy.sign: -1 / 0 / +1, NaN stays NaN
 template <class T>
 EKM_HD T m_sign(T x) {
@@ -516,24 +520,34 @@ EKM_HD float wbpt_direct(float e) {
 EKM_HD float bisect_step(float r, float dt) { return (r < 0.0f || r > 0.0f) ? __builtin_copysignf(dt, r) : r; }
 EKM_HD double bisect_step(double r, double dt) { return (r < 0.0 || r > 0.0) ? __builtin_copysign(dt, r) : r; }
 
-// Moist-adiabat inversion by 12 fixed halvings (thermo.py:1055-1079)
-// IFS variant of the 12 halvings with the loop-invariant (p0/p)^kappa hoisted and the two
-// divisions of G_sat = -K0*qs/t merged into one reciprocal (same residual, thermo.py:1075,1177-1182).
+// Moist-adiabat inversion by 12 fixed halvings (thermo.py:1055-1079), IFS variant, table-free statement (host twin;
+// the gfx950 kernels run t_on_ma_bisect_ifs_tab below, the same arithmetic with es_mixed read from an LDS table).
+//  * The reference's residual ept*exp(G_sat) - t*(p0/p)^kappa (thermo.py:1075) is divided by the positive per-point
+//    constant (p0/p)^kappa: r = te*exp2(g) - t with te = ept*(p/p0)^kappa has the same sign and costs one fma.
+//  * The two divisions of G_sat = -K0*qs/t (thermo.py:1177-1182) are merged into one reciprocal.
+//  * The reference's mask `p - es < eps -> NaN` (thermo.py:192-196; it makes t NaN from that step on) is applied ONCE
+//    after the search: fl(p - es) is non-increasing in es, so "some visited lattice point had p - es < eps" is exactly
+//    "p - max(es visited) < eps".  Outside the mask v = p - 0.378*es > 0, so the unmasked steps stay finite.
 template <class T>
-EKM_HD T t_on_ma_bisect_ifs(T e, T p) {
-  const T thf = m_exp2(T(-k::kappa) * m_log2(p * T(1.0 / k::p0)));
+EKM_HD T t_on_ma_bisect_ifs_te(T te, T p) {
   T t = T(k::T0 - 20);
   T dt = T(120.0);
+  T esmax = T(0);
 #pragma unroll 1
   for (int it = 0; it < 12; ++it) {
     const T es = es_mixed(t);
-    T v = p + T(k::eps - 1) * es;
-    if ((p - es) < T(k::eps_default)) v = nan_v<T>();
-    const T g = T(-k::K0_ifs * k::eps * k::LOG2E) * es * m_rcp(v * t);  // log2 of exp(-K0*qs/t)
+    esmax = m_max(esmax, es);
+    const T g = T(-k::K0_ifs * k::eps * k::LOG2E) * es * m_rcp((p + T(k::eps - 1) * es) * t);  // log2 of exp(-K0*qs/t)
     dt *= T(0.5);
-    t += bisect_step(e * m_exp2(g) - t * thf, dt);
+    t += bisect_step(te * m_exp2(g) - t, dt);
   }
+  if ((p - esmax) < T(k::eps_default)) t = nan_v<T>();
   return t;
+}
+
+template <class T>
+EKM_HD T t_on_ma_bisect_ifs(T e, T p) {
+  return t_on_ma_bisect_ifs_te(e * m_exp2(T(k::kappa) * m_log2(p * T(1.0 / k::p0))), p);
 }
 
 // The same 12 halvings with es_mixed read from a table.  The search only ever evaluates the saturated
@@ -550,32 +564,101 @@ EKM_HD T bisect_lattice_t(int m) {
   return T(k::T0 - 20) + T(m - kBisectLattice / 2) * T(120.0 / 2048);
 }
 
-// `thf` = (p0/p)^kappa, `e` = theta_e.  The lattice index is recovered from t itself (t is exactly on the
-// lattice, so (t - 253.16)*2048/120 + 2048 is an integer up to rounding far below 1/2; NaN converts to 0,
-// a valid entry -- the result is NaN from then on anyway).
-template <class T>
-EKM_HD T t_on_ma_bisect_ifs_tab(T e, T p, T thf, const T* __restrict__ es_tab) {
+// One lattice entry: es_m = es_mixed(t_m) and, in fp32, a second value beside it -- the factor of the step's exponent
+// that depends on the lattice temperature alone (LDS: 32 KiB per workgroup in either precision):
+//   ifs       a_m = -K0*eps*log2(e)*es_m/t_m      exponent = a_m * rcp(p + (eps-1)*es_m)
+//   bolton35  a_m = -2675*log2(e)/t_m             exponent = kl + ws*(a_m - 0.28*kl),  kl = kappa*log2(p/p0)
+//   bolton39  a_m = (-3036/t_m + 1.78)*log2(e)    exponent = a_m*ws*(1 + 0.448*ws) + kappa*log2((p - es_m)/p0)
+// fp64 tabulates es alone and forms a_m from t with one reciprocal.
+template <int METHOD, class T>
+EKM_HD T bisect_second(T es, T rt) {  // rt = 1/t_m
+  if (METHOD == EPT_IFS) return T(-k::K0_ifs * k::eps * k::LOG2E) * es * rt;
+  if (METHOD == EPT_BOLTON35) return T(-2675.0 * k::LOG2E) * rt;
+  return (T(-3036.0) * rt + T(1.78)) * T(k::LOG2E);
+}
+
+template <int METHOD, class T>
+struct BisectEntry;
+template <int METHOD>
+struct BisectEntry<METHOD, float> {
+  static constexpr int width = 2;
+  EKM_HD static void fill(float* __restrict__ tab, int m) {
+    const float t = bisect_lattice_t<float>(m), es = es_mixed(t);
+    tab[2 * m] = es;
+    tab[2 * m + 1] = bisect_second<METHOD>(es, 1.0f / t);  // IEEE division: once per workgroup
+  }
+  EKM_HD static void load(const float* __restrict__ tab, int m, float, float& es, float& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = reinterpret_cast<const f2*>(tab)[m];  // one ds_read_b64
+    es = v[0];
+    a = v[1];
+#else
+    es = tab[2 * m];
+    a = tab[2 * m + 1];
+#endif
+  }
+};
+template <int METHOD>
+struct BisectEntry<METHOD, double> {
+  static constexpr int width = 1;
+  EKM_HD static void fill(double* __restrict__ tab, int m) { tab[m] = es_mixed(bisect_lattice_t<double>(m)); }
+  EKM_HD static void load(const double* __restrict__ tab, int m, double t, double& es, double& a) {
+    es = tab[m];
+    a = bisect_second<METHOD>(es, m_rcp(t));
+  }
+};
+
+// The 12 halvings on the table.  `e`: for ifs te = theta_e*(p/p0)^kappa, for the Bolton methods theta_e itself.
+// The reference's residual ept*exp(G_sat) - th_sat (thermo.py:1075) is divided by the positive th_sat/t:
+// r = e*exp2(g) - t has the same sign and costs ONE exp2 and one fma per step.  For ifs th_sat/t = (p0/p)^kappa is a
+// per-point constant (already folded into te; the wet-bulb from q then needs no power of the pressure at all); for
+// bolton35 / bolton39 (thermo.py:1215-1224, 1280-1295) it is the step's own (p0/p)^(kappa*(1-0.28*ws)) resp.
+// (p0/(p-es))^kappa, whose exponent joins g.  The reference's mask `p - es < eps -> NaN` (thermo.py:192-196, 229-232,
+// 1283-1284: it makes t NaN from that step on) is applied ONCE after the search: fl(p - es) is non-increasing in es, so
+// "some visited lattice point had p - es < eps" is exactly "p - max(es visited) < eps" -- one v_max per step instead of
+// a subtract, a compare and a select.  Outside the mask p - es >= eps > 0, so the unmasked steps stay finite.
+// The lattice index is recovered from t itself (t is exactly on the lattice, so (t - 253.16)*2048/120 + 2048 is an
+// integer up to rounding far below 1/2; NaN converts to 0, a valid entry -- the result is NaN from then on anyway).
+template <int METHOD, class T>
+EKM_HD T t_on_ma_bisect_tab(T e, T p, const T* __restrict__ tab) {
   T t = T(k::T0 - 20);
   T dt = T(120.0);
+  T esmax = T(0);
+  T kl = T(0);
+  if (METHOD == EPT_BOLTON35) kl = T(k::kappa) * m_log2(p * T(1.0 / k::p0));
 #ifndef EKM_BISECT_UNROLL
 #define EKM_BISECT_UNROLL 12
 #endif
 #pragma unroll EKM_BISECT_UNROLL
   for (int it = 0; it < 12; ++it) {
-    const int m = (int)(t * T(2048.0 / 120.0) + T(kBisectLattice / 2 + 0.5 - (k::T0 - 20) * (2048.0 / 120.0)));
-    const T es = es_tab[m];
-    T v = p + T(k::eps - 1) * es;
-    if ((p - es) < T(k::eps_default)) v = nan_v<T>();
-    const T g = T(-k::K0_ifs * k::eps * k::LOG2E) * es * m_rcp(v * t);  // log2 of exp(-K0*qs/t)
+    int m = (int)(t * T(2048.0 / 120.0) + T(kBisectLattice / 2 + 0.5 - (k::T0 - 20) * (2048.0 / 120.0)));
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (!(t == t)) m = 0;  // v_cvt_i32_f32 turns NaN into 0; the host conversion is undefined
+#endif
+    T es, a, g;
+    BisectEntry<METHOD, T>::load(tab, m, t, es, a);
+    esmax = m_max(esmax, es);
+    if (METHOD == EPT_IFS) {
+      g = a * m_rcp(p + T(k::eps - 1) * es);  // log2 of exp(-K0*qs/t)
+    } else {
+      const T v = p - es;
+      const T ws = T(k::eps) * es * m_rcp(v);
+      if (METHOD == EPT_BOLTON35)
+        g = kl + ws * (a - T(0.28) * kl);
+      else
+        g = a * ws * (T(1) + T(0.448) * ws) + T(k::kappa) * m_log2(v * T(1.0 / k::p0));
+    }
     dt *= T(0.5);
-    t += bisect_step(e * m_exp2(g) - t * thf, dt);
+    t += bisect_step(e * m_exp2(g) - t, dt);
   }
+  if ((p - esmax) < T(k::eps_default)) t = nan_v<T>();
   return t;
 }
 
 template <class T>
-EKM_HD T t_on_ma_bisect_ifs_tab(T e, T p, const T* __restrict__ es_tab) {
-  return t_on_ma_bisect_ifs_tab(e, p, m_exp2(T(-k::kappa) * m_log2(p * T(1.0 / k::p0))), es_tab);
+EKM_HD T t_on_ma_bisect_ifs_tab(T te, T p, const T* __restrict__ tab) {
+  return t_on_ma_bisect_tab<EPT_IFS>(te, p, tab);
 }
 
 template <int METHOD, class T>
@@ -723,18 +806,17 @@ EKM_HD Regime davies_regime(T c_te, T cd, T p, const TeExact& te_exact, Tie& tie
 template <class T>
 struct PTerms {
   T p;     // pressure (Pa)
+  T l;     // log2(p/p0): (p/p0)^kappa = exp2(kappa*l) is formed only where a regime 2-4 guess needs it (thermo.py:1109)
   T thf;   // (p0/p)^kappa   (thermo.py:829)
-  T pp;    // (p/p0)^kappa   (thermo.py:1109)
   T dinv;  // 0.1859e-5*p + 0.6512 = 1/D(p)   (thermo.py:1100-1102)
 };
 
 template <class T>
 EKM_HD PTerms<T> pterms(T p) {
   PTerms<T> r;
-  const T l = m_log2(p * T(1.0 / k::p0));
+  r.l = m_log2(p * T(1.0 / k::p0));
   r.p = p;
-  r.thf = m_exp2(T(-k::kappa) * l);
-  r.pp = m_exp2(T(k::kappa) * l);
+  r.thf = m_exp2(T(-k::kappa) * r.l);
   r.dinv = T(0.1859e-5) * p + T(0.6512);
   return r;
 }
@@ -745,16 +827,23 @@ EKM_HD PTerms<T> pterms(T p) {
 // the negated exponent, the Newton residual 1 - c_te/f from ONE exp2 (the exponents of c_te, c_tw and
 // exp(G) add), reciprocals shared between qs and its slope, and regime / phase work skipped by whole
 // waves that do not need it.  `lte` = log2(te/273.16); `te` itself is only needed by the regime-1 guess.
-template <class T, class TeExact, class Tie>
-EKM_HD T t_on_ma_newton_ifs_core(T e, T te, T lte, T p, T pp, T dinv, const TeExact& te_exact, Tie& tie) {
+// `te_fn()` = te and `pp_fn()` = (p/p0)^kappa are evaluated lazily, inside the wave-uniform branches that need them:
+// te only feeds the regime-1 guess, (p/p0)^kappa only the guesses of regimes 2-4 (thermo.py:1114-1128), and regimes
+// are coherent along a level -- a wave of cold upper-level points never forms the pressure power, a wave of warm
+// points never forms te (one log2 + one exp2 resp. one exp2 per point, and the k1/k2 polynomials).
+template <class T, class TeFn, class PpFn, class TeExact, class Tie>
+EKM_HD T t_on_ma_newton_ifs_core(T lte, T p, T dinv, const TeFn& te_fn, const PpFn& pp_fn, const TeExact& te_exact,
+                                 Tie& tie) {
   const T lam = T(k::lambda);
   const T c_te = m_exp2(-lam * lte);  // (t0/te)^lambda
   const T cd = c_te * dinv;           // c_te / D
   const Regime R = davies_regime(c_te, cd, p, te_exact, tie);
 
-  // initial guess in deg C; later regimes overwrite earlier ones (thermo.py:1114-1128)
-  T tw = e;
+  // initial guess in deg C; later regimes overwrite earlier ones (thermo.py:1114-1128).  No regime holds only for a
+  // NaN c_te, i.e. a NaN lte: the reference then carries ept through one Newton step against a NaN c_te -- NaN.
+  T tw = lte;
   if (EKM_ANY(R.r1)) {
+    const T te = te_fn();
     T es, des;
     es_slope_mixed(te, es, des);
     T v = p - es;
@@ -766,14 +855,17 @@ EKM_HD T t_on_ma_newton_ifs_core(T e, T te, T lte, T p, T pp, T dinv, const TeEx
     const T g1 = (te - T(273.16)) - aw * m_rcp(T(1) + bw);
     if (R.r1) tw = g1;
   }
-  const T k1 = poly2(pp, -53.737, 137.81, -38.5);
-  const T k2 = poly2(pp, -0.384, 56.831, -4.392);
-  const T k2m = k2 - T(1.21);
-  if (R.r2) tw = k1 - k2 * c_te;
-  if (R.r3) tw = (k1 - T(1.21)) - k2m * c_te;
-  if (EKM_ANY(R.r4)) {
-    const T g4 = (k1 - T(2.66)) - k2m * c_te + T(0.58) * m_exp2(lam * lte);  // 0.58/c_te
-    if (R.r4) tw = g4;
+  if (EKM_ANY(R.r2 || R.r3 || R.r4)) {
+    const T pp = pp_fn();
+    const T k1 = poly2(pp, -53.737, 137.81, -38.5);
+    const T k2 = poly2(pp, -0.384, 56.831, -4.392);
+    const T k2m = k2 - T(1.21);
+    if (R.r2) tw = k1 - k2 * c_te;
+    if (R.r3) tw = (k1 - T(1.21)) - k2m * c_te;
+    if (EKM_ANY(R.r4)) {
+      const T g4 = (k1 - T(2.66)) - k2m * c_te + T(0.58) * m_exp2(lam * lte);  // 0.58/c_te
+      if (R.r4) tw = g4;
+    }
   }
   tw = tw + T(k::T0);
 
@@ -801,9 +893,11 @@ EKM_HD T t_on_ma_newton_ifs_core(T e, T te, T lte, T p, T pp, T dinv, const TeEx
 // theta_e given (temperature_on_moist_adiabat, wet-bulb from dewpoint, theta_w by Newton)
 template <class T, class Tie>
 EKM_HD T t_on_ma_newton_ifs(T e, const PTerms<T>& P, Tie& tie) {
-  const T te = e * P.pp;  // thermo.py:1110
+  // te = ept*(p/p0)^kappa (thermo.py:1110); its logarithm needs no power of the pressure
   const TeFromEpt<T> exact{e, P.p};
-  return t_on_ma_newton_ifs_core(e, te, m_log2(te * T(1.0 / 273.16)), P.p, P.pp, P.dinv, exact, tie);
+  const T kl = T(k::kappa) * P.l;
+  return t_on_ma_newton_ifs_core(m_log2(e * T(1.0 / 273.16)) + kl, P.p, P.dinv, [&] { return e * m_exp2(kl); },
+                                 [&] { return m_exp2(kl); }, exact, tie);
 }
 
 // te = theta_e*(p/p0)^kappa for the IFS theta_e from specific humidity (thermo.py:1169-1175 with td from
@@ -904,7 +998,14 @@ EKM_HD T t_on_ma_newton(T e, T p, Tie& tie) {
 template <int METHOD, int TM, class T, class Tie>
 EKM_HD T t_on_ma(T e, T p, Tie& tie) {  // thermo.py:1472-1509
   if (TM == T_BISECT) return t_on_ma_bisect<METHOD>(e, p);
-  if (METHOD == EPT_IFS) return t_on_ma_newton_ifs(e, pterms(p), tie);
+  if (METHOD == EPT_IFS) {
+    PTerms<T> P;  // (p0/p)^kappa is not needed here
+    P.p = p;
+    P.l = m_log2(p * T(1.0 / k::p0));
+    P.thf = T(0);
+    P.dinv = T(0.1859e-5) * p + T(0.6512);
+    return t_on_ma_newton_ifs(e, P, tie);
+  }
   return t_on_ma_newton<METHOD>(e, p, tie);
 }
 

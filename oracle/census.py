@@ -74,7 +74,8 @@ def bisect_job(job):
     where its fp32 and fp64 runs disagree."""
     np.seterr(all="ignore")
     t, q, p, got = job["t"], job["q"], job["p"], job["got"]
-    want = orc.wet_bulb_temperature_from_specific_humidity(t, q, p, "ifs", "bisect")
+    method = job.get("method", "ifs")
+    want = orc.wet_bulb_temperature_from_specific_humidity(t, q, p, method, "bisect")
     g64, w64 = got.astype(np.float64), np.asarray(want, np.float64)
     quantum = 120.0 / 4096.0
     nanmm = np.isnan(g64) != np.isnan(w64)
@@ -87,8 +88,8 @@ def bisect_job(job):
     if differ.any():  # classify the differing points only (the fp64 reference run is the expensive part)
         idx = np.flatnonzero(differ)
         noisy, noise_t = conditioning.bisect_sign_noise("wet_bulb_temperature_from_specific_humidity",
-                                                        [t[idx], q[idx], p[idx]], {}, 3e-6, return_points=True)
-        w_true = orc.wet_bulb_temperature_from_specific_humidity(*(x[idx].astype(np.float64) for x in (t, q, p)), "ifs", "bisect")
+                                                        [t[idx], q[idx], p[idx]], {"ept_method": method}, 3e-6, return_points=True)
+        w_true = orc.wet_bulb_temperature_from_specific_humidity(*(x[idx].astype(np.float64) for x in (t, q, p)), method, "bisect")
         w32, g = w64[idx], g64[idx]
         unstable = (np.isnan(w32) != np.isnan(w_true)) | (np.abs(w32 - w_true) > 0.5 * quantum)
         # NO point is exempt from a check (tests/_compare.py::_assert_bisect): a differing value must be a NaN that the
@@ -133,8 +134,8 @@ def slot_job(spec):
     lo, hi = spec["lo"], spec["hi"]
     t, q, p = a[0, lo:hi], a[1, lo:hi], a[2, lo:hi]
     got = [a[3 + k, lo:hi] for k in range(spec["nrows"] - 3)]
-    if spec["kind"] == "bisect":
-        return bisect_job(dict(t=t, q=q, p=p, got=got[0]))
+    if spec["kind"].startswith("bisect"):  # "bisect" (ifs), "bisect:bolton35", "bisect:bolton39"
+        return bisect_job(dict(t=t, q=q, p=p, got=got[0], method=(spec["kind"].split(":") + ["ifs"])[1]))
     return job(dict(kind=spec["kind"], t=t, q=q, p=p, got=got, tw_index=spec["tw_index"], tol=spec["tol"]))
 
 

@@ -22,6 +22,10 @@ W = {  # workload: entry, operands, ints, nout, bytes/pt (field p)
     "full": ("pipeline_full", "tqp", (), 6, 36), "p3": ("pipeline_svp_td_rh", "tqp", (), 3, 24),
     "wetbulb": ("wet_bulb_temperature_from_specific_humidity", "tqp", (0, 1), 1, 16),
     "wetbulb_bisect": ("wet_bulb_temperature_from_specific_humidity", "tqp", (0, 0), 1, 16),
+    "wetbulb_bisect_bolton35": ("wet_bulb_temperature_from_specific_humidity", "tqp", (1, 0), 1, 16),
+    "wetbulb_bisect_bolton39": ("wet_bulb_temperature_from_specific_humidity", "tqp", (2, 0), 1, 16),
+    "wetbulb_td": ("wet_bulb_temperature_from_dewpoint", "tqp", (0, 1), 1, 16),
+    "t_on_ma_bisect": ("temperature_on_moist_adiabat", "tp", (0, 0), 1, 12),
     "rh": ("relative_humidity_from_specific_humidity", "tqp", (), 1, 16),
     "ept": ("ept_from_specific_humidity", "tqp", (0,), 1, 16),
     "theta": ("potential_temperature", "tp", (), 1, 12), "svp": ("saturation_vapour_pressure", "t", (0,), 1, 8),
@@ -32,8 +36,9 @@ W = {  # workload: entry, operands, ints, nout, bytes/pt (field p)
 def load(path):
     lib = C.CDLL(path)
     for name, (args, res) in _ffi._signatures().items():
-        fn = getattr(lib, name)
-        fn.argtypes, fn.restype = args, res
+        fn = getattr(lib, name, None)  # an older variant library may lack the newest entry points
+        if fn is not None:
+            fn.argtypes, fn.restype = args, res
     return lib
 
 
