@@ -481,7 +481,7 @@ int tuning_tiles_per_block();
 int tuning_unroll();
 int tuning_lev_per_wg();    // EKM_HYBRID_FULL: consecutive levels one workgroup walks (EKM_LEV_PER_WG, default 0 = by stream count)
 int tuning_hybrid_band_bytes();  // EKM_HYBRID_FULL: bytes of surface pressure per band (EKM_HYBRID_BAND_KB, default 8192 KiB)
-int tuning_table_tiles();   // tiles per workgroup for ops that build an LDS table (EKM_TABLE_TILES, default 16)
+int tuning_table_tiles();   // most tiles per workgroup for ops that build an LDS table (EKM_TABLE_TILES, default 64)
 int tuning_geo_chunk_levels();  // levels per launch of the geopotential column scan (EKM_GEO_CHUNK_LEVELS, default: all in one launch)
 
 constexpr unsigned kMaxLdsBytes = 64 * 1024;
@@ -572,7 +572,14 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
   const unsigned long long ntile = (nchunk + kThreads - 1) / kThreads;
   unsigned tiles = (unsigned)tuning_tiles_per_block();
   // an op that builds an LDS table per workgroup amortises it over more tiles (bisection: 4096 es values)
-  if (OpTable<Op>::elems > 0 && tiles < (unsigned)tuning_table_tiles()) tiles = (unsigned)tuning_table_tiles();
+  // (filling the 4096-entry lattice costs a workgroup about as much as 2000 points: at 64 tiles = 65536 points per
+  // workgroup that is 3 % -- but never so many tiles that a medium-sized call leaves compute units idle)
+  if (OpTable<Op>::elems > 0 && tiles < (unsigned)tuning_table_tiles()) {
+    const int cus = device_cus(dev);
+    unsigned long long fill = ntile / (4ull * (unsigned long long)(cus > 0 ? cus : 256));  // >= 4 workgroups per CU
+    if (fill < 4) fill = 4;
+    tiles = (unsigned)(fill < (unsigned long long)tuning_table_tiles() ? fill : (unsigned long long)tuning_table_tiles());
+  }
   const int unroll = tuning_unroll();
   if (!bc && aligned && unroll >= 2) tiles = (tiles + 1u) & ~1u;  // the unrolled body takes tiles in pairs
   // keep the grid within the launch limit for very large fields

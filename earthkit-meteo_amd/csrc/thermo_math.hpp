@@ -846,13 +846,11 @@ EKM_HD T t_on_ma_newton_ifs_core(T lte, T p, T dinv, const TeFn& te_fn, const Pp
     const T te = te_fn();
     T es, des;
     es_slope_mixed(te, es, des);
+    // te - t0 - A*ws/(1 + A*ws*des/es) with ws = eps*es/v, v = p - es (thermo.py:1116-1119): the two divisions are one,
+    // A*eps*es/(v + A*eps*des).  v is NaN where p - es < eps, and es <= 0 (underflow) is the reference's 0*0/0.
     T v = p - es;
-    if (v < T(k::eps_default)) v = nan_v<T>();
-    const T rv = m_rcp(v);
-    const T aw = T(2675 * k::eps) * es * rv;   // A*ws
-    T bw = T(2675 * k::eps) * des * rv;        // A*ws*des/es
-    if (!(es > T(0))) bw = nan_v<T>();         // the reference's 0*0/0 where es underflows
-    const T g1 = (te - T(273.16)) - aw * m_rcp(T(1) + bw);
+    if (v < T(k::eps_default) || !(es > T(0))) v = nan_v<T>();
+    const T g1 = (te - T(273.16)) - T(2675 * k::eps) * es * m_rcp(v + T(2675 * k::eps) * des);
     if (R.r1) tw = g1;
   }
   if (EKM_ANY(R.r2 || R.r3 || R.r4)) {
@@ -871,21 +869,22 @@ EKM_HD T t_on_ma_newton_ifs_core(T lte, T p, T dinv, const TeFn& te_fn, const Pp
 
   // one Newton step (thermo.py:1132-1149, 1184-1197): tw -= (f - c_te)/(f*dlnf) = (1 - c_te/f)/dlnf with
   // c_te/f = exp2(lambda*(log2(tw/t0) - log2(te/t0)) + lambda*K0*log2(e)*qs/tw)
-  const T rtw = m_rcp(tw);
+  // With qr = qs/tw and dqs the mixed-phase slope of qs (thermo.py:418-467): dlnf = -lambda*(1/tw + K0*(dqs - qr)/tw), so
+  // the step is tw*(1 - ratio)/(lambda*(1 + K0*(dqs - qr))): two reciprocals -- 1/(v*tw), shared by qr and dqs, and the
+  // step's denominator -- instead of three.
   const T ltw = m_log2(tw * T(1.0 / 273.16));
   T es, des;
   es_slope_mixed(tw, es, des);
   T v = p + T(k::eps - 1) * es;
   if ((p - es) < T(k::eps_default)) v = nan_v<T>();
-  const T rv = m_rcp(v);
-  const T qs = T(k::eps) * es * rv;
-  const T qr = qs * rtw;
+  const T r2 = m_rcp(v * tw);
+  const T rv = r2 * tw;
+  const T qr = T(k::eps) * es * r2;
   const T ratio = m_exp2(lam * (ltw - lte) + T(k::lambda * k::K0_ifs * k::LOG2E) * qr);
-  const T dqs = T(k::eps) * des * p * (rv * rv);
-  const T dg = T(k::K0_ifs) * rtw * (dqs - qr);
-  const T dlnf = -lam * (rtw + dg);
+  const T dqs = (T(k::eps) * p) * des * (rv * rv);
+  const T den = T(1) + T(k::K0_ifs) * (dqs - qr);
   // f == 0 (tw -> inf) or f == inf make the reference's (f - c_te)/(f*dlnf) NaN; so does ratio = inf/NaN here
-  tw -= (T(1) - ratio) * m_rcp(dlnf);
+  tw += ((T(1) - ratio) * T(1.0 / k::lambda)) * m_rcp(den) * tw;
   if (tw <= T(0)) tw = nan_v<T>();  // thermo.py:1155
   return tw;
 }

@@ -201,7 +201,7 @@ EKM_API int ekm_get_tuning(int* tiles_per_block, int* unroll);
 /* secondary parameters by name (defaults from the environment, in brackets):
  *   "hybrid_band_kb" [EKM_HYBRID_BAND_KB, 8192]  EKM_HYBRID_FULL: KiB of surface pressure per L2-resident band;
  *   "lev_per_wg"     [EKM_LEV_PER_WG, 0]         EKM_HYBRID_FULL: consecutive levels one workgroup walks (0 = by stream count);
- *   "table_tiles"    [EKM_TABLE_TILES, 16]       tiles per workgroup for ops that build an LDS table (bisection);
+ *   "table_tiles"    [EKM_TABLE_TILES, 64]       most tiles per workgroup for ops that build an LDS table (bisection);
  *   "geo_chunk_levels" [EKM_GEO_CHUNK_LEVELS, all] levels per launch of the geopotential column scan. */
 EKM_API int ekm_set_tuning_param(const char* name, int value);
 
