@@ -346,7 +346,9 @@ def main():
         if p is not None:
             op_p = F(p.ptr, _ffi.FIELD, 0, 0, 0)
         elif args.pmode == "hybrid":
-            op_p = F(hyb["sp"].ptr, _ffi.HYBRID_FULL, 0, nlev_loc, ncol, hyb["A"].ptr, hyb["B"].ptr)
+            nz = np.flatnonzero(hyb["Bh"] != 0.0)  # leading pure pressure levels of this shard's table (ekm_operand.nflat)
+            nflat = int(max(0, (nz[0] if nz.size else hyb["Bh"].size) - 1))
+            op_p = F(hyb["sp"].ptr, _ffi.HYBRID_FULL, nflat, nlev_loc, ncol, hyb["A"].ptr, hyb["B"].ptr)
         else:  # level vector: a shard starts on a level boundary (plan_shard) and passes the sub-vector of its levels
             assert first % INNER == 0, "level mode needs level-aligned shards"
             op_p = F(plev.ptr + lev0 * itemsize, _ffi.LEVEL_MAJOR, 0, nlev_loc, INNER)

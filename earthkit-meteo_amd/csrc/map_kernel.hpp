@@ -20,8 +20,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
+#include <mutex>
 
 #include "../../include/ekm_thermo.h"
 #include "ops.hpp"
@@ -126,10 +128,33 @@ __device__ __forceinline__ void apply_points(const T (&x)[V][Op::NIN], T (&y)[V]
   }
 }
 
+// The table does not depend on the inputs: it is computed ONCE per device into a __device__ array (fill_op_table, on
+// the first use of the op on that device: launch_map::ensure_op_table) and every workgroup copies its 32 KiB from
+// there -- an L2-resident read of eight 16-B vectors per thread -- instead of recomputing 4096 x (es_mixed + a
+// division), which cost a workgroup as much as ~2000 grid points and forced 64-tile workgroups to amortise it.
+// (static: every translation unit is its own device module with its own copy, and its own `ready` flags below)
+template <class Tab, class T>
+static __device__ __attribute__((aligned(16))) T g_op_table[Tab::template count<T>() > 0 ? Tab::template count<T>() : 4];
+
+template <class Tab, class T>
+static __global__ __launch_bounds__(kThreads) void fill_op_table() {
+  Tab::template fill<T>(g_op_table<Tab, T>, (int)(blockIdx.x * kThreads + threadIdx.x), (int)(gridDim.x * kThreads));
+}
+
+template <class Tab, class T>
+__device__ __forceinline__ void load_op_table(T* __restrict__ lds) {
+  typedef typename VecOf<T>::type Vec;
+  constexpr int NV = Tab::template count<T>() / VecOf<T>::N;  // the counts are multiples of the vector width
+  const Vec* __restrict__ src = reinterpret_cast<const Vec*>(g_op_table<Tab, T>);
+  Vec* __restrict__ dst = reinterpret_cast<Vec*>(lds);
+#pragma unroll 4
+  for (int i = threadIdx.x; i < NV; i += kThreads) dst[i] = src[i];
+}
+
 #define EKM_OP_TABLE(Op, T, name)                                              \
-  __shared__ T name[OpTable<Op>::elems > 0 ? OpTable<Op>::template count<T>() : 1]; \
+  __shared__ __attribute__((aligned(16))) T name[OpTable<Op>::elems > 0 ? OpTable<Op>::template count<T>() : 4]; \
   if constexpr (OpTable<Op>::elems > 0) {                                      \
-    OpTable<Op>::template fill<T>(name, (int)threadIdx.x, kThreads);           \
+    load_op_table<typename OpTable<Op>::table_type, T>(name);                  \
     __syncthreads();                                                           \
   }
 
@@ -338,29 +363,38 @@ __global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, 
 //    one-in one-out op, slower once several streams are open, each then with lev_per_wg windows
 //    (profiles/r02_sweep_hybrid.txt).
 // No per-lane position bookkeeping, no integer division, no LDS: a tile never straddles levels.
-enum { PM_LEVEL = 0, PM_HYBRID = 1 };
+enum { PM_LEVEL = 0, PM_HYBRID = 1, PM_FLAT = 2 };
 
 template <class T, int NIN, int NOUT>
 struct LevArgs {
-  const T* in[NIN];  // fields; in[NIN-1] = the level vector (PM_LEVEL) or the surface pressure (PM_HYBRID)
+  const T* in[NIN];  // fields; in[NIN-1] = the level vector (PM_LEVEL) or the surface pressure (PM_HYBRID, PM_FLAT)
   T* out[NOUT];
-  const T* A;        // PM_HYBRID: half-level tables, last + 2 values each
+  const T* A;        // PM_HYBRID / PM_FLAT: half-level tables, last + 2 values each
   const T* B;
   unsigned long long n;  // grid points
   unsigned inner;        // points per level (< 2^31)
   unsigned nlev;         // levels covered by n points = ceil(n / inner)
   unsigned last;         // highest valid index of the level vector / full-level index
-  unsigned lev_per_wg;   // consecutive levels one workgroup walks (PM_LEVEL: 1)
+  unsigned lev_per_wg;   // consecutive levels one workgroup walks (WALK instantiation only; else 1)
   unsigned tiles;        // consecutive horizontal tiles per workgroup
   T rp;
 };
 
-template <class Op, class T, int PMODE, bool ALIGNED>
-__global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_levels(const LevArgs<T, Op::NIN, Op::NOUT> a) {
+// PM_FLAT: the pure pressure levels of a hybrid table (B[k] = B[k+1] = 0: the upper 53 of the 137 IFS levels).  The
+// host layer passes their count (ekm_operand.nflat) and launch_map runs them as a launch of their own: p does not
+// depend on sp there, so the level runs exactly like a level-vector one -- pressure-only sub-expressions once per
+// chunk instead of once per point -- without a second copy of the body inside the hybrid kernel (which cost the
+// six-output pipeline occupancy).  The reference's p = A + B*sp is NaN for a non-finite sp even when B = 0: lanes
+// whose surface pressure is not finite (never in real data) are redone point by point with that NaN.
+// WALK (PM_HYBRID only): the workgroup walks `lev_per_wg` > 1 consecutive levels of its tile with sp and the shared
+// half-level pressure in registers.
+template <class Op, class T, int PMODE, bool ALIGNED, bool WALK = false>
+__global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? OpWaves<Op>::value : EKM_WAVES_PER_EU)) void map_levels(const LevArgs<T, Op::NIN, Op::NOUT> a) {
   constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N, PI = Op::NIN - 1;
   typedef typename VecOf<T>::type Vec;
   EKM_OP_TABLE(Op, T, op_tab)
-  const unsigned k0 = blockIdx.y * a.lev_per_wg;  // wave-uniform
+  const unsigned lpw = WALK ? a.lev_per_wg : 1u;
+  const unsigned k0 = blockIdx.y * lpw;  // wave-uniform
 
   for (unsigned i = 0; i < a.tiles; ++i) {
     const unsigned long long tile = (unsigned long long)blockIdx.z * gridDim.x + blockIdx.x;
@@ -368,10 +402,9 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_levels(const L
     if (col64 >= a.inner) continue;
     const unsigned col = (unsigned)col64;
 
-    T ph0[V], s[V];  // PM_HYBRID: lower half-level pressure carried up the column, surface pressure
-    T a0 = T(0), b0 = T(1);
-    bool sp_finite = true;  // wave-uniform: every lane's surface pressure is finite
-    if (PMODE == PM_HYBRID) {
+    T ph0[V], s[V];  // PM_HYBRID: lower half-level pressure (carried up the column when WALK), surface pressure
+    bool sp_ok = true;  // PM_FLAT: this lane's surface pressures are all finite
+    if (PMODE == PM_HYBRID || PMODE == PM_FLAT) {
       const T* sp = a.in[PI];
       if (ALIGNED && col + V <= a.inner) {
         const Vec sv = *reinterpret_cast<const Vec*>(sp + col);  // cached load: other level groups re-read it
@@ -381,19 +414,20 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_levels(const L
 #pragma unroll
         for (int j = 0; j < V; ++j) s[j] = (col + j < a.inner) ? sp[col + j] : T(1);
       }
-      const unsigned kk = k0 <= a.last ? k0 : a.last;
-      a0 = a.A[kk];
-      b0 = a.B[kk];
-      bool fin = true;
+      if (PMODE == PM_FLAT) {
+        T sum = s[0];
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        ph0[j] = a0 + b0 * s[j];
-        fin = fin && (s[j] - s[j] == T(0));
+        for (int j = 1; j < V; ++j) sum += s[j];
+        sp_ok = (sum - sum == T(0));  // surface pressures are ~1e5: the sum is finite iff every one of them is
+      } else if (WALK) {
+        const unsigned kk = k0 <= a.last ? k0 : a.last;
+        const T a0 = a.A[kk], b0 = a.B[kk];
+#pragma unroll
+        for (int j = 0; j < V; ++j) ph0[j] = a0 + b0 * s[j];
       }
-      sp_finite = __builtin_amdgcn_ballot_w64(!fin) == 0ull;
     }
 
-    for (unsigned l = 0; l < a.lev_per_wg; ++l) {
+    for (unsigned l = 0; l < lpw; ++l) {
       const unsigned k = k0 + l;
       if (k >= a.nlev) break;
       const unsigned kk = k <= a.last ? k : a.last;
@@ -404,6 +438,20 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_levels(const L
       const unsigned long long e0 = row + col;
 
       // one level of this lane's chunk, pressure given per point by `pressure(j)`
+      auto run_points = [&](auto pressure, auto wanted) {  // element by element, the points with wanted(j)
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          if (col + j < rowlen && wanted(j)) {
+            T x[NIN], y[NOUT];
+#pragma unroll
+            for (int f = 0; f < PI; ++f) x[f] = a.in[f][e0 + j];
+            x[PI] = pressure(j);
+            op_apply<Op, T>(x, y, a.rp, op_tab);
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) a.out[o][e0 + j] = y[o];
+          }
+        }
+      };
       auto run_level = [&](auto pressure) {
         if (ALIGNED && col + V <= rowlen) {
           Vec xin[NIN > 1 ? NIN - 1 : 1], yout[NOUT];
@@ -424,47 +472,37 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_levels(const L
           }
 #pragma unroll
           for (int o = 0; o < NOUT; ++o) st_stream<T>(a.out[o] + e0, yout[o]);
-        } else {  // unaligned rows / ragged end of a row: element by element
-#pragma unroll
-          for (int j = 0; j < V; ++j) {
-            if (col + j < rowlen) {
-              T x[NIN], y[NOUT];
-#pragma unroll
-              for (int f = 0; f < PI; ++f) x[f] = a.in[f][e0 + j];
-              x[PI] = pressure(j);
-              op_apply<Op, T>(x, y, a.rp, op_tab);
-#pragma unroll
-              for (int o = 0; o < NOUT; ++o) a.out[o][e0 + j] = y[o];
-            }
-          }
+        } else {  // unaligned rows / ragged end of a row
+          run_points(pressure, [](int) { return true; });
         }
       };
 
       if (PMODE == PM_HYBRID) {
         const T a1 = a.A[kk + 1], b1 = a.B[kk + 1];
-        // Only for the VALU-bound single-output ops (wet-bulb family: 3.74 -> 3.36 ms): the second copy of the body
-        // buys nothing for HBM-bound ops and costs the six-output pipeline occupancy and instruction cache
-        // (5.67 -> 5.9 ms), so those take the general branch on every level.
-        constexpr bool kFlatLevels = NOUT == 1 && (OpUsesTie<Op>::value || OpTable<Op>::elems > 0);
-        if (kFlatLevels && b0 == T(0) && b1 == T(0) && sp_finite) {
-          // a pure pressure level (the upper 53 of the 137 IFS levels): p does not depend on sp, so the level runs
-          // like a level-vector one -- pressure-only sub-expressions once per chunk instead of once per point
-          const T pl = a0 + T(0.5) * (a1 - a0);
-          run_level([&](int) { return pl; });
-#pragma unroll
-          for (int j = 0; j < V; ++j) ph0[j] = a1;
-        } else {
-          T pv[V];
+        T pv[V];
+        if (WALK) {
 #pragma unroll
           for (int j = 0; j < V; ++j) {
             const T ph1 = a1 + b1 * s[j];
             pv[j] = ph0[j] + T(0.5) * (ph1 - ph0[j]);
             ph0[j] = ph1;
           }
-          run_level([&](int j) { return pv[j]; });
+        } else {
+          const T a0 = a.A[kk], b0 = a.B[kk];
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            const T pl0 = a0 + b0 * s[j], ph1 = a1 + b1 * s[j];
+            pv[j] = pl0 + T(0.5) * (ph1 - pl0);
+          }
         }
-        a0 = a1;
-        b0 = b1;
+        run_level([&](int j) { return pv[j]; });
+      } else if (PMODE == PM_FLAT) {
+        const T a0 = a.A[kk], a1 = a.A[kk + 1];
+        const T pl = a0 + T(0.5) * (a1 - a0);  // (vertical.py:670, 708 with B = 0)
+        run_level([&](int) { return pl; });
+        if (__builtin_amdgcn_ballot_w64(!sp_ok) != 0ull) {  // a non-finite surface pressure: p = A + 0*sp is NaN there
+          if (!sp_ok) run_points([&](int j) { return pl + (s[j] - s[j]); }, [&](int j) { return !(s[j] - s[j] == T(0)); });
+        }
       } else {
         const T pl = a.in[PI][kk];
         run_level([&](int) { return pl; });
@@ -481,10 +519,38 @@ int tuning_tiles_per_block();
 int tuning_unroll();
 int tuning_lev_per_wg();    // EKM_HYBRID_FULL: consecutive levels one workgroup walks (EKM_LEV_PER_WG, default 0 = by stream count)
 int tuning_hybrid_band_bytes();  // EKM_HYBRID_FULL: bytes of surface pressure per band (EKM_HYBRID_BAND_KB, default 8192 KiB)
-int tuning_table_tiles();   // most tiles per workgroup for ops that build an LDS table (EKM_TABLE_TILES, default 64)
+int tuning_table_tiles();   // most tiles per workgroup for ops that keep an LDS table (EKM_TABLE_TILES, default 8)
 int tuning_geo_chunk_levels();  // levels per launch of the geopotential column scan (EKM_GEO_CHUNK_LEVELS, default: all in one launch)
 
 constexpr unsigned kMaxLdsBytes = 64 * 1024;
+
+// Per-device, once: compute the op's table into its __device__ array.  Outside stream capture the fill runs on the
+// caller's stream and is waited for (the only host wait a launch function ever does, once per device and table), so that
+// launches on any other stream may read the table afterwards.  Under capture the fill is recorded into the graph in
+// front of the kernel that needs it and the table is NOT marked ready (the captured work has not run).
+template <class Tab, class T>
+static int ensure_op_table(int dev, hipStream_t s) {
+  static std::atomic<unsigned long long> ready{0};  // bit per device
+  static std::mutex mu;
+  if (dev < 0 || dev >= 64) return set_error(EKM_ERR_NODEV, "device %d out of range", dev);
+  if (ready.load(std::memory_order_acquire) >> dev & 1ull) return EKM_OK;
+  std::lock_guard<std::mutex> lk(mu);
+  if (ready.load(std::memory_order_acquire) >> dev & 1ull) return EKM_OK;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+    (void)hipGetLastError();
+    st = hipStreamCaptureStatusNone;
+  }
+  hipLaunchKernelGGL((fill_op_table<Tab, T>), dim3(16), dim3(kThreads), 0, s);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return set_error(EKM_ERR_HIP, "table fill launch: %s", hipGetErrorString(err));
+  if (st == hipStreamCaptureStatusNone) {
+    err = hipStreamSynchronize(s);
+    if (err != hipSuccess) return set_error(EKM_ERR_HIP, "table fill: %s", hipGetErrorString(err));
+    ready.fetch_or(1ull << dev, std::memory_order_release);
+  }
+  return EKM_OK;
+}
 
 template <class Op, class T>
 int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const* outs, size_t n, double rp) {
@@ -492,6 +558,10 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
   if (n == 0) return EKM_OK;
   int rc = use_device(dev);
   if (rc != EKM_OK) return rc;
+  if constexpr (OpTable<Op>::elems > 0) {
+    rc = ensure_op_table<typename OpTable<Op>::table_type, T>(dev, static_cast<hipStream_t>(stream));
+    if (rc != EKM_OK) return rc;
+  }
   MapArgs<T, NIN, NOUT> a;
   a.aux0 = a.aux1 = nullptr;
   a.n = n;
@@ -572,13 +642,12 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
   const unsigned long long ntile = (nchunk + kThreads - 1) / kThreads;
   unsigned tiles = (unsigned)tuning_tiles_per_block();
   // an op that builds an LDS table per workgroup amortises it over more tiles (bisection: 4096 es values)
-  // (filling the 4096-entry lattice costs a workgroup about as much as 2000 points: at 64 tiles = 65536 points per
-  // workgroup that is 3 % -- but never so many tiles that a medium-sized call leaves compute units idle)
+  // an op with an LDS table copies 32 KiB per workgroup from the device-resident table: a few tiles amortise that
   if (OpTable<Op>::elems > 0 && tiles < (unsigned)tuning_table_tiles()) {
     const int cus = device_cus(dev);
-    unsigned long long fill = ntile / (4ull * (unsigned long long)(cus > 0 ? cus : 256));  // >= 4 workgroups per CU
-    if (fill < 4) fill = 4;
-    tiles = (unsigned)(fill < (unsigned long long)tuning_table_tiles() ? fill : (unsigned long long)tuning_table_tiles());
+    unsigned long long most = ntile / (4ull * (unsigned long long)(cus > 0 ? cus : 256));  // >= 4 workgroups per CU
+    if (most < 1) most = 1;
+    tiles = (unsigned)(most < (unsigned long long)tuning_table_tiles() ? most : (unsigned long long)tuning_table_tiles());
   }
   const int unroll = tuning_unroll();
   if (!bc && aligned && unroll >= 2) tiles = (tiles + 1u) & ~1u;  // the unrolled body takes tiles in pairs
@@ -607,20 +676,17 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
       const unsigned long long nlev = (n + inner - 1) / inner;
       // hybrid: 0 = auto: a one-in one-out op (theta: 8 B/pt) gains from walking 4 levels per workgroup with sp and
       // the shared half-level pressure in registers (1.29 -> 1.16 ms); with more streams open it loses (P3 3.01 -> 3.28 ms)
-      la.lev_per_wg = 1u;
-      if (pm == EKM_HYBRID_FULL) la.lev_per_wg = tuning_lev_per_wg() > 0 ? (unsigned)tuning_lev_per_wg() : (NIN - 1 + NOUT <= 2 ? 4u : 1u);
-      if (la.lev_per_wg > nlev) la.lev_per_wg = (unsigned)nlev;
-      const unsigned long long gy = (nlev + la.lev_per_wg - 1) / la.lev_per_wg;
+      unsigned lpw = 1u;
+      if (pm == EKM_HYBRID_FULL) lpw = tuning_lev_per_wg() > 0 ? (unsigned)tuning_lev_per_wg() : (NIN - 1 + NOUT <= 2 ? 4u : 1u);
       // shapes this kernel is not meant for go to map_bcast: rows longer than 32-bit columns, more level
       // groups than gridDim.y allows, or rows much shorter than a workgroup (a vector along a short axis)
-      const bool fits = inner < (1ull << 31) && gy <= 65535ull && (inner >= (unsigned long long)kThreads || pm == EKM_HYBRID_FULL);
+      const bool fits = inner < (1ull << 31) && nlev <= 65535ull && (inner >= (unsigned long long)kThreads || pm == EKM_HYBRID_FULL);
       if (!fits && pm == EKM_HYBRID_FULL)
         return set_error(EKM_ERR_ARG, "EKM_HYBRID_FULL: inner = %llu, len = %u is outside the supported range", inner,
                          a.len[NIN - 1]);
       levels = fits;
       if (levels) {
         la.inner = (unsigned)inner;
-        la.nlev = (unsigned)nlev;
         la.tiles = OpTable<Op>::elems > 0 ? tiles : 1u;
         const unsigned long long per_wg = (unsigned long long)kThreads * V * la.tiles;
         const unsigned long long ntx = (inner + per_wg - 1) / per_wg;  // workgroups along one level
@@ -632,20 +698,49 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
           if (band > ntx) band = ntx;
           while ((ntx + band - 1) / band > 65535ull) band *= 2;
         }
-        const dim3 g((unsigned)band, (unsigned)gy, (unsigned)((ntx + band - 1) / band));
         // rows start 16-B aligned when the row length is a multiple of the vector width -- or when there is only one
         // row (a scalar operand with any n): its ragged end is handled by the kernel's own `col + V <= rowlen` test
         const bool al = aligned && (inner % V == 0 || nlev == 1);
+        // one launch over the levels [k_lo, k_hi) of the call: pointers, tables and counts rebased to k_lo
+        auto launch_part = [&](int pmode, unsigned k_lo, unsigned k_hi, unsigned walk) {
+          LevArgs<T, NIN, NOUT> q = la;
+          const unsigned long long off = (unsigned long long)k_lo * inner;
+          for (int i = 0; i + 1 < NIN; ++i) q.in[i] = la.in[i] + off;
+          for (int o = 0; o < NOUT; ++o) q.out[o] = la.out[o] + off;
+          if (pmode == PM_LEVEL) {
+            q.in[NIN - 1] = la.in[NIN - 1] + (pm == EKM_SCALAR ? 0u : k_lo);
+          } else {
+            q.A = la.A + k_lo;
+            q.B = la.B + k_lo;
+          }
+          q.last = la.last >= k_lo ? la.last - k_lo : 0u;
+          const unsigned long long hi_pts = (unsigned long long)k_hi * inner;
+          q.n = (hi_pts < n ? hi_pts : n) - off;
+          q.nlev = k_hi - k_lo;
+          q.lev_per_wg = walk < q.nlev ? walk : q.nlev;
+          const unsigned gy = (q.nlev + q.lev_per_wg - 1) / q.lev_per_wg;
+          const dim3 g((unsigned)band, gy, (unsigned)((ntx + band - 1) / band));
+#define EKM_LEV_LAUNCH(PM_, AL_, WALK_) hipLaunchKernelGGL((map_levels<Op, T, PM_, AL_, WALK_>), g, dim3(kThreads), 0, s, q)
+          if (pmode == PM_LEVEL) {
+            if (al) EKM_LEV_LAUNCH(PM_LEVEL, true, false); else EKM_LEV_LAUNCH(PM_LEVEL, false, false);
+          } else if (pmode == PM_FLAT) {
+            if (al) EKM_LEV_LAUNCH(PM_FLAT, true, false); else EKM_LEV_LAUNCH(PM_FLAT, false, false);
+          } else if (q.lev_per_wg > 1) {
+            if (al) EKM_LEV_LAUNCH(PM_HYBRID, true, true); else EKM_LEV_LAUNCH(PM_HYBRID, false, true);
+          } else {
+            if (al) EKM_LEV_LAUNCH(PM_HYBRID, true, false); else EKM_LEV_LAUNCH(PM_HYBRID, false, false);
+          }
+#undef EKM_LEV_LAUNCH
+        };
         if (pm == EKM_HYBRID_FULL) {
-          if (al)
-            hipLaunchKernelGGL((map_levels<Op, T, PM_HYBRID, true>), g, dim3(kThreads), 0, s, la);
-          else
-            hipLaunchKernelGGL((map_levels<Op, T, PM_HYBRID, false>), g, dim3(kThreads), 0, s, la);
+          // the leading `nflat` levels are pure pressure levels (B = 0 on both half levels; the host layer counts
+          // them, ekm_operand.nflat): they run as a level-vector launch of their own, the rest as the hybrid kernel
+          unsigned nflat = ins[NIN - 1]->nflat > 0 ? (unsigned)ins[NIN - 1]->nflat : 0u;
+          if (nflat > nlev) nflat = (unsigned)nlev;
+          if (nflat > 0) launch_part(PM_FLAT, 0u, nflat, 1u);
+          if (nflat < nlev) launch_part(PM_HYBRID, nflat, (unsigned)nlev, lpw);
         } else {
-          if (al)
-            hipLaunchKernelGGL((map_levels<Op, T, PM_LEVEL, true>), g, dim3(kThreads), 0, s, la);
-          else
-            hipLaunchKernelGGL((map_levels<Op, T, PM_LEVEL, false>), g, dim3(kThreads), 0, s, la);
+          launch_part(PM_LEVEL, 0u, (unsigned)nlev, 1u);
         }
       }
     }

@@ -6,6 +6,13 @@
 
 #include "thermo_math.hpp"
 
+#ifndef EKM_WAVES_PER_EU_DEFAULT
+#define EKM_WAVES_PER_EU_DEFAULT 1
+#endif
+#ifndef EKM_P5_WAVES
+#define EKM_P5_WAVES 5
+#endif
+
 namespace ekm {
 
 #define EKM_OP(NAME, NIN_, NOUT_, ...)                                      \
@@ -182,6 +189,7 @@ struct OpTable {
 // (thermo_math.hpp::BisectEntry: fp32 pairs (es_m, a_m), fp64 es_m alone; 32 KiB either way).
 template <int METHOD>
 struct BisectTable {
+  typedef BisectTable<METHOD> table_type;  // all ops of one theta_e method share one device-resident table
   static constexpr int elems = kBisectLattice;
   template <class T>
   static constexpr int count() {
@@ -343,6 +351,18 @@ struct OpPipelineFull {
 template <>
 struct OpUsesTie<OpPipelineFull> {
   static constexpr bool value = true;
+};
+
+// Waves per SIMD a kernel of this op should be compiled for (launch bounds: caps the register allocation).
+// The six-output pipeline sits at 97-106 VGPRs in the per-level kernels, two registers above the 96 that allow a
+// fifth wave per SIMD; it is HBM-bound, so the extra wave in flight is worth more than the registers.
+template <class Op>
+struct OpWaves {
+  static constexpr int value = EKM_WAVES_PER_EU_DEFAULT;
+};
+template <>
+struct OpWaves<OpPipelineFull> {
+  static constexpr int value = EKM_P5_WAVES;
 };
 
 }  // namespace ekm

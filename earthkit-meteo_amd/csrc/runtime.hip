@@ -100,7 +100,7 @@ struct Param {
 static Param g_params[] = {
     {"lev_per_wg", "EKM_LEV_PER_WG", 0, 0, 1024},
     {"hybrid_band_kb", "EKM_HYBRID_BAND_KB", 8192, 4, 1 << 20},
-    {"table_tiles", "EKM_TABLE_TILES", 64, 1, 4096},
+    {"table_tiles", "EKM_TABLE_TILES", 8, 1, 4096},
     {"geo_chunk_levels", "EKM_GEO_CHUNK_LEVELS", 1 << 20, 1, 1 << 20},
 };
 static int param(int i) {

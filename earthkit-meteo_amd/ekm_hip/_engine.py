@@ -410,7 +410,8 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
             tabs = [DeviceArray.from_host(x.astype(plan.dtype), device=dev) for x in (hp.A, hp.B)]
             temps.extend(tabs + ([sp] if sp is not a else []))
             inner = max(1, sp.size)
-            operands.append(_ffi.Operand(sp.ptr, _ffi.HYBRID_FULL, 0, hp.nlev, inner, tabs[0].ptr, tabs[1].ptr))
+            # (a B that is zero in double stays zero in the compute dtype, so the count holds for the uploaded table)
+            operands.append(_ffi.Operand(sp.ptr, _ffi.HYBRID_FULL, hp.nflat, hp.nlev, inner, tabs[0].ptr, tabs[1].ptr))
             continue
         shape = a.shape
         cls = classify(shape, plan.shape) if plan.n else (_ffi.FIELD, 0, 0)

@@ -29,7 +29,7 @@ class EkmLibraryError(ImportError):
 
 
 class Operand(C.Structure):
-    _fields_ = [("data", C.c_void_p), ("mode", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("data", C.c_void_p), ("mode", C.c_int32), ("nflat", C.c_int32),
                 ("len", C.c_uint64), ("inner", C.c_uint64), ("aux0", C.c_void_p), ("aux1", C.c_void_p)]
 
 

@@ -327,6 +327,10 @@ class HybridPressure:
             raise ValueError("A and B must be 1-D half-level tables of the same length >= 2")
         self.sp = sp
         self.nlev = self.A.size - 1
+        # leading pure pressure levels (B = 0 on both half levels: the upper 53 of the 137 IFS levels): the library runs
+        # them at level-vector speed in a launch of their own (ekm_operand.nflat)
+        nz = np.flatnonzero(self.B != 0.0)
+        self.nflat = int(max(0, (nz[0] if nz.size else self.B.size) - 1))
 
     @property
     def shape(self):

@@ -1,6 +1,6 @@
 // The compute entry points of libekm_thermo.so allocate nothing, copy nothing and do not synchronise:
 // they can be recorded into a hipGraph and replayed (include/ekm_thermo.h "Conventions").
-// Captures ekm_pipeline_svp_td_rh_f32 + ekm_wet_bulb_temperature_from_specific_humidity_f32 on a stream,
+// Captures ekm_pipeline_svp_td_rh_f32 + ekm_wet_bulb_temperature_from_specific_humidity_f32 (Newton and bisection) on a stream,
 // replays the graph on fresh inputs and compares with direct launches.  Exit code 0 = identical.
 #include <hip/hip_runtime.h>
 
@@ -33,9 +33,9 @@ int main() {
     printf("no device: %s\n", ekm_last_error());
     return 4;
   }
-  float *t, *q, *p, *o[4], *r[4];
+  float *t, *q, *p, *o[5], *r[5];
   for (float** x : {&t, &q, &p}) EKM(ekm_malloc(0, n * 4, (void**)x));
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 5; ++i) {
     EKM(ekm_malloc(0, n * 4, (void**)&o[i]));
     EKM(ekm_malloc(0, n * 4, (void**)&r[i]));
   }
@@ -50,19 +50,23 @@ int main() {
   CHK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
   EKM(ekm_pipeline_svp_td_rh_f32(0, s, &ot, &oq, &op, o[0], o[1], o[2], n));
   EKM(ekm_wet_bulb_temperature_from_specific_humidity_f32(0, s, &ot, &oq, &op, EKM_EPT_IFS, EKM_T_NEWTON, o[3], n));
+  // the bisection keeps a device-resident lattice table, computed on first use: this IS the first use, so the fill is
+  // recorded into the graph in front of the kernel (and not marked done: the direct launch below fills it again)
+  EKM(ekm_wet_bulb_temperature_from_specific_humidity_f32(0, s, &ot, &oq, &op, EKM_EPT_IFS, EKM_T_BISECT, o[4], n));
   CHK(hipStreamEndCapture(s, &graph));
   hipGraphExec_t exec;
   CHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
 
   for (int round = 0; round < 3; ++round) {
     EKM(ekm_synth_fill_f32(0, s, t, q, p, 0, n, n / 8, 8, 100 + round));  // new inputs, same buffers
-    for (int i = 0; i < 4; ++i) CHK(hipMemsetAsync(o[i], 0xff, n * 4, s));
+    for (int i = 0; i < 5; ++i) CHK(hipMemsetAsync(o[i], 0xff, n * 4, s));
     CHK(hipGraphLaunch(exec, s));
     EKM(ekm_pipeline_svp_td_rh_f32(0, s, &ot, &oq, &op, r[0], r[1], r[2], n));
     EKM(ekm_wet_bulb_temperature_from_specific_humidity_f32(0, s, &ot, &oq, &op, EKM_EPT_IFS, EKM_T_NEWTON, r[3], n));
+    EKM(ekm_wet_bulb_temperature_from_specific_humidity_f32(0, s, &ot, &oq, &op, EKM_EPT_IFS, EKM_T_BISECT, r[4], n));
     CHK(hipStreamSynchronize(s));
     std::vector<float> a(n), b(n);
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 5; ++i) {
       CHK(hipMemcpy(a.data(), o[i], n * 4, hipMemcpyDeviceToHost));
       CHK(hipMemcpy(b.data(), r[i], n * 4, hipMemcpyDeviceToHost));
       if (std::memcmp(a.data(), b.data(), n * 4) != 0) {

@@ -156,7 +156,9 @@ extern "C" {
 typedef struct ekm_operand {
   const void* data; /* device pointer (float* for _f32, double* for _f64)         */
   int32_t mode;     /* EKM_FIELD / EKM_SCALAR / EKM_LEVEL_MAJOR / EKM_LEVEL_MINOR */
-  int32_t reserved; /* 0                                                           */
+  int32_t nflat;    /* EKM_HYBRID_FULL: number of LEADING levels k with B[k] = B[k+1] = 0 (pure pressure
+                       levels: the upper 53 of the 137 IFS levels), which then run at level-vector
+                       speed in a launch of their own; 0 is always valid.  Else 0.            */
   uint64_t len;     /* vector length for the LEVEL modes, else ignored            */
   uint64_t inner;   /* points per level for EKM_LEVEL_MAJOR / EKM_HYBRID_FULL      */
   const void* aux0; /* EKM_HYBRID_FULL: A table (device), else NULL                */
@@ -201,7 +203,7 @@ EKM_API int ekm_get_tuning(int* tiles_per_block, int* unroll);
 /* secondary parameters by name (defaults from the environment, in brackets):
  *   "hybrid_band_kb" [EKM_HYBRID_BAND_KB, 8192]  EKM_HYBRID_FULL: KiB of surface pressure per L2-resident band;
  *   "lev_per_wg"     [EKM_LEV_PER_WG, 0]         EKM_HYBRID_FULL: consecutive levels one workgroup walks (0 = by stream count);
- *   "table_tiles"    [EKM_TABLE_TILES, 64]       most tiles per workgroup for ops that build an LDS table (bisection);
+ *   "table_tiles"    [EKM_TABLE_TILES, 8]        most tiles per workgroup for ops that keep an LDS table (bisection);
  *   "geo_chunk_levels" [EKM_GEO_CHUNK_LEVELS, all] levels per launch of the geopotential column scan. */
 EKM_API int ekm_set_tuning_param(const char* name, int value);
 

@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--pmode", default="field")
     ap.add_argument("--out", default="")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--nflat", type=int, default=-1, help="hybrid: leading pure pressure levels passed to the library (-1 = count them)")
     ap.add_argument("--skew", default="0", help="comma list: byte offset added to the k-th array's base (k*skew)")
     ap.add_argument("--params", default="", help="secondary parameters to sweep, e.g. hybrid_band_kb=512:4096:32768,"
                                                    "lev_per_wg=1:2 (ekm_set_tuning_param); the cross product is run")
@@ -104,7 +105,7 @@ def main():
         chk(base.ekm_sync(dev))
     ops = {"t": F(t, 0, 0, 0, 0), "q": F(q, 0, 0, 0, 0),
            "p": F(p, 0, 0, 0, 0) if a.pmode == "field" else (
-               F(pl, 2, 0, a.levels, INNER) if a.pmode == "level" else F(hyb[2], 4, 0, a.levels, INNER, hyb[0], hyb[1]))}
+               F(pl, 2, 0, a.levels, INNER) if a.pmode == "level" else F(hyb[2], 4, a.nflat if a.nflat >= 0 else int(max(0, np.flatnonzero(B != 0)[0] - 1)), a.levels, INNER, hyb[0], hyb[1]))}
     W["geopotential"] = ("geopotential_on_hybrid_levels", "", (), 1, 12)
     pnames = [kv.split("=")[0] for kv in a.params.split(",") if kv]
     pvals = [[int(v) for v in kv.split("=")[1].split(":")] for kv in a.params.split(",") if kv]
