@@ -180,6 +180,9 @@ EKM_API int ekm_free(int dev, void* ptr);
 EKM_API int ekm_host_alloc(size_t bytes, void** out);  /* pinned host memory for fast transfers */
 EKM_API int ekm_host_free(void* ptr);
 EKM_API int ekm_host_prefault(void* ptr, size_t bytes, int nthreads); /* fault in every page of a host buffer; never changes its contents */
+EKM_API int ekm_host_memcpy(void* dst, const void* src, size_t bytes, int nthreads); /* host-to-host copy on `nthreads` threads (staging through pinned buffers) */
+EKM_API int ekm_host_register(void* ptr, size_t bytes);   /* pin caller-owned host memory in place (hipHostRegister) */
+EKM_API int ekm_host_unregister(void* ptr);
 EKM_API int ekm_h2d(int dev, void* dst, const void* src, size_t bytes, void* stream);
 EKM_API int ekm_d2h(int dev, void* dst, const void* src, size_t bytes, void* stream);
 EKM_API int ekm_d2d(int dev, void* dst, const void* src, size_t bytes, void* stream);
