@@ -334,6 +334,113 @@ int ekm_host_memcpy(void* dst, const void* src, size_t bytes, int nthreads) {
   return EKM_OK;
 }
 
+// ---- staged transfers: pageable caller memory <-> device through pinned ring buffers --------------------------
+// Measured on the GPU box (tools/host_link_probe.py, profiles/r03_host_link_probe.txt): the link moves 57 GB/s per
+// direction and 96 GB/s in both at once from pinned memory; a pageable hipMemcpyAsync reaches that only for copies
+// of hundreds of MB (the runtime pins in place chunk by chunk) and drops to ~30 GB/s per direction for the 26-MB
+// slices the streamed path moves.  Here `nthreads` host threads each run a small pipeline over interleaved chunks:
+// memcpy into (out of) their own pinned slots at ~30 GB/s each, DMA on the caller's stream.
+namespace ekm {
+constexpr size_t kStageChunk = 8u << 20;
+constexpr int kStageMaxThreads = 8, kStageSlotsPerThread = 2;
+struct StageRing {
+  std::mutex mu;  // one job at a time per device and direction
+  void* buf[kStageMaxThreads * kStageSlotsPerThread] = {};
+  hipEvent_t ev[kStageMaxThreads * kStageSlotsPerThread] = {};
+  bool pending[kStageMaxThreads * kStageSlotsPerThread] = {};
+  bool init = false;
+};
+static StageRing g_stage[kMaxDev][2];
+
+struct StageChunk {
+  char* dst;
+  const char* src;
+  size_t len;
+};
+}  // namespace ekm
+
+int ekm_copy_staged(int dev, int to_device, int nseg, void* const* dst, const void* const* src, const size_t* bytes,
+                    void* stream, int nthreads) {
+  if (nseg <= 0) return EKM_OK;
+  if (!dst || !src || !bytes) return set_error(EKM_ERR_ARG, "copy_staged: null argument");
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > kStageMaxThreads) nthreads = kStageMaxThreads;
+  std::vector<StageChunk> chunks;
+  for (int i = 0; i < nseg; ++i) {
+    if (bytes[i] == 0) continue;
+    if (!dst[i] || !src[i]) return set_error(EKM_ERR_ARG, "copy_staged: segment %d has a null pointer", i);
+    for (size_t off = 0; off < bytes[i]; off += kStageChunk)
+      chunks.push_back({static_cast<char*>(dst[i]) + off, static_cast<const char*>(src[i]) + off,
+                        bytes[i] - off < kStageChunk ? bytes[i] - off : kStageChunk});
+  }
+  if (chunks.empty()) return EKM_OK;
+  if ((size_t)nthreads > chunks.size()) nthreads = (int)chunks.size();
+  StageRing& ring = g_stage[dev][to_device ? 1 : 0];
+  std::lock_guard<std::mutex> lk(ring.mu);
+  if (!ring.init) {
+    for (int k = 0; k < kStageMaxThreads * kStageSlotsPerThread; ++k) {
+      EKM_HIP(hipHostMalloc(&ring.buf[k], kStageChunk, hipHostMallocDefault));
+      EKM_HIP(hipEventCreateWithFlags(&ring.ev[k], hipEventDisableTiming));
+    }
+    ring.init = true;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::atomic<int> failed{0};
+  auto worker = [&](int w) {
+    if (hipSetDevice(dev) != hipSuccess) {
+      failed.store(1);
+      return;
+    }
+    auto ok = [&](hipError_t e) {
+      if (e != hipSuccess) failed.store(1);
+      return e == hipSuccess;
+    };
+    const int base = w * kStageSlotsPerThread;
+    if (to_device) {
+      int turn = 0;
+      for (size_t c = (size_t)w; c < chunks.size(); c += (size_t)nthreads, turn ^= 1) {
+        const int slot = base + turn;
+        if (ring.pending[slot] && !ok(hipEventSynchronize(ring.ev[slot]))) return;  // its last DMA must have left it
+        memcpy(ring.buf[slot], chunks[c].src, chunks[c].len);
+        if (!ok(hipMemcpyAsync(chunks[c].dst, ring.buf[slot], chunks[c].len, hipMemcpyHostToDevice, s))) return;
+        if (!ok(hipEventRecord(ring.ev[slot], s))) return;
+        ring.pending[slot] = true;
+      }
+    } else {
+      // two slots per thread: the DMA of chunk k+1 is in flight while chunk k is copied out to the caller's memory
+      long prev = -1;
+      int prev_slot = 0, turn = 0;
+      for (size_t c = (size_t)w; c < chunks.size(); c += (size_t)nthreads, turn ^= 1) {
+        const int slot = base + turn;
+        if (!ok(hipMemcpyAsync(ring.buf[slot], chunks[c].src, chunks[c].len, hipMemcpyDeviceToHost, s))) return;
+        if (!ok(hipEventRecord(ring.ev[slot], s))) return;
+        if (prev >= 0) {
+          if (!ok(hipEventSynchronize(ring.ev[prev_slot]))) return;
+          memcpy(chunks[prev].dst, ring.buf[prev_slot], chunks[prev].len);
+        }
+        prev = (long)c;
+        prev_slot = slot;
+      }
+      if (prev >= 0) {
+        if (!ok(hipEventSynchronize(ring.ev[prev_slot]))) return;
+        memcpy(chunks[prev].dst, ring.buf[prev_slot], chunks[prev].len);
+      }
+      for (int k = 0; k < kStageSlotsPerThread; ++k) ring.pending[base + k] = false;
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int w = 1; w < nthreads; ++w) pool.emplace_back(worker, w);
+  worker(0);
+  for (auto& th : pool) th.join();
+  if (failed.load()) {
+    hipError_t e = hipGetLastError();
+    return set_error(EKM_ERR_HIP, "copy_staged: %s", e != hipSuccess ? hipGetErrorString(e) : "a staged transfer failed");
+  }
+  return EKM_OK;
+}
+
 int ekm_host_register(void* ptr, size_t bytes) {
   if (!ptr || bytes == 0) return set_error(EKM_ERR_ARG, "host_register: null pointer or empty range");
   int rc = probe();

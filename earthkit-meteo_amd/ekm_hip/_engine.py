@@ -170,6 +170,7 @@ def leading_axis_bounds(n0, nshards):
 
 _streams = {}
 _streams_lock = threading.Lock()
+_STAGED = os.environ.get("EKM_STAGED", "1") != "0"  # streamed path: transfers through the pinned staging ring
 _MAX_LANES = 8            # slices in flight per GPU when memory allows (upload of one overlaps download of another)
 _MIN_SLICE_BYTES = 16 << 20  # do not cut finer than this: small copies waste PCIe bandwidth
 _BLOCK_OVERHEAD = (1 << 20) + 16 * (20 << 10)  # worst-case rounding + stagger padding of one device block
@@ -209,13 +210,15 @@ def stream_budget_bytes(dev):
     return min(budget, int(cap)) if cap else budget
 
 
-def plan_slices(rows, row_bytes, budget, max_lanes=_MAX_LANES, min_slice=_MIN_SLICE_BYTES, overhead=0):
+def plan_slices(rows, row_bytes, budget, max_lanes=_MAX_LANES, min_slice=_MIN_SLICE_BYTES, overhead=0,
+                pref_slice=256 << 20):
     """How to stream `rows` leading-axis rows of `row_bytes` device bytes each (inputs + outputs) through a
     device working set of at most `budget` bytes: returns (lanes, nslices) -- `lanes` slices are in flight at
     a time, each lane recycling its device blocks from slice to slice, and
     lanes * ceil(rows / nslices) * row_bytes <= budget.
-      * everything fits: one slice per lane, up to `max_lanes` lanes, slices of at least `min_slice` bytes
-        (small copies waste PCIe bandwidth; a small call is one slice);
+      * everything fits: up to `max_lanes` lanes, slices of at least `min_slice` bytes (small copies waste PCIe
+        bandwidth; a small call is one slice) and, for big calls, of about `pref_slice` bytes (more slices than lanes:
+        a short pipeline ramp; the lanes recycle their device blocks);
       * it does not fit: as many lanes as the budget allows with slices of at least `min_slice` (8, 4), at
         least two (double buffering) whatever the slice size; None if two single-row slices do not fit.
     `overhead`: device bytes every in-flight slice costs on top of its rows (allocator rounding and stagger)."""
@@ -224,7 +227,10 @@ def plan_slices(rows, row_bytes, budget, max_lanes=_MAX_LANES, min_slice=_MIN_SL
         return 1, 1
     lanes = int(max(1, min(max_lanes, rows, total // min_slice)))
     if total + lanes * overhead <= budget:
-        return lanes, lanes
+        # everything fits.  More slices than lanes still pay: the transfers of the first slice up and of the last
+        # slice down overlap with nothing, so slices of about `pref_slice` bytes keep that ramp short for big calls
+        nslices = int(max(lanes, min(rows, total // pref_slice)))
+        return lanes, nslices
     for lanes in (8, 4, 2):
         if lanes > max(max_lanes, 2) or lanes > rows:
             continue
@@ -301,15 +307,20 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
             for ev in ready.values():
                 ev.set()
 
+    trace = [] if os.environ.get("EKM_TRACE_STREAM") else None
+    import time as _time
+
     def uploader(dev, mine, depth, slots, handoff, most):
         # ONE host-to-device copy in flight per GPU: concurrent pageable uploads collapse (207 MB in 1 / 2 / 4 / 8
         # threads: 48 / 53 / 19 / 16 GB/s), while an upload and a download run together at full rate (PCIe duplex)
         try:
             set_device(dev)
             for k, (lo, hi) in enumerate(mine):
+                t0 = _time.perf_counter()
                 slots.acquire()  # at most `depth` slices resident on the device
                 if errors:
                     break
+                t1 = _time.perf_counter()
                 set_stream(_lane_stream(dev, k % depth))
                 # operands that span the leading axis get the matching slice; everything else is passed as
                 # the caller gave it (a Python scalar must stay a weak scalar for the dtype promotion)
@@ -317,7 +328,9 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
                 # slices differ by one row: every slice's device blocks are sized for the LONGEST slice, so a lane takes
                 # back exactly the blocks it released (same bucket) and the footprint stays lanes x slice, live + cached
                 handoff.put(((lo, hi), _submit(name, part, ints, eps, dtype, host_out=[o[lo:hi] for o in outs],
-                                               reserve_rows=(hi - lo, most))))
+                                               reserve_rows=(hi - lo, most), staged=_STAGED)))
+                if trace is not None:
+                    trace.append(("up", k, t0, t1, _time.perf_counter()))
         except BaseException as exc:  # surfaced in the calling thread
             errors.append(exc)
         finally:
@@ -335,9 +348,13 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
                 sl, pend = item
                 try:
                     if not errors:
+                        t0 = _time.perf_counter()
                         ready[sl].wait()
+                        t1 = _time.perf_counter()
                         set_stream(pend.stream)
                         _collect(pend)
+                        if trace is not None:
+                            trace.append(("down", sl[0], t0, t1, _time.perf_counter()))
                 finally:
                     slots.release()
         except BaseException as exc:
@@ -356,13 +373,17 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
         th.join()
     if errors:
         raise errors[0]
+    if trace is not None:  # EKM_TRACE_STREAM=1: when each slice waited / moved (ms since the first event)
+        z = min(e[2] for e in trace)
+        for kind, k, t0, t1, t2 in sorted(trace, key=lambda e: e[2]):
+            print(f"[stream] {kind:4s} slice {k:4d}: wait {1e3 * (t0 - z):7.2f} -> {1e3 * (t1 - z):7.2f}, work -> {1e3 * (t2 - z):7.2f} ms")
     return tuple(outs)
 
 
 class _Pending:
     """One submitted launch: device results (and the temporaries its operands live in) not yet collected."""
 
-    __slots__ = ("plan", "results", "temps", "host_out", "internal_out", "toucher", "stream")
+    __slots__ = ("plan", "results", "temps", "host_out", "internal_out", "toucher", "stream", "staged")
 
 
 def _reserved(nbytes, reserve_rows):
@@ -378,7 +399,21 @@ def _run_single(name, args, ints=(), eps=None, dtype=None, host_out=None, touche
     return _collect(_submit(name, args, ints, eps, dtype, host_out, toucher))
 
 
-def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=None, reserve_rows=None):
+_STAGE_THREADS = int(os.environ.get("EKM_STAGE_THREADS", "4"))  # host copy threads per direction of a staged transfer
+
+
+def _copy_staged(dev, to_device, pairs, stream):
+    """One pipelined job through the library's pinned staging ring (ekm_copy_staged): `pairs` = [(dst, src, nbytes)]."""
+    n = len(pairs)
+    if not n:
+        return
+    dst = (C.c_void_p * n)(*[p[0] for p in pairs])
+    src = (C.c_void_p * n)(*[p[1] for p in pairs])
+    nb = (C.c_size_t * n)(*[p[2] for p in pairs])
+    _ffi.check(_ffi.lib().ekm_copy_staged(dev, int(to_device), n, dst, src, nb, stream, _STAGE_THREADS))
+
+
+def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=None, reserve_rows=None, staged=False):
     """Upload what lives on the host, launch, return without waiting for the kernel (the uploads themselves are
     synchronous copies on the current stream).  `reserve_rows` = (rows of this slice, rows of the longest slice):
     field-sized device blocks are reserved at the longest slice's size (streamed path)."""
@@ -392,6 +427,7 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
 
     temps = []  # device buffers owned by this call
     operands = []
+    uploads = []  # staged: (device pointer, host pointer, bytes, the host array kept alive)
     lds_bytes = 0
     internal_out = False  # host_out allocated here (compute dtype) rather than supplied by the caller
     if not plan.on_device and host_out is None and plan.n * plan.dtype.itemsize >= _PRETOUCH_BYTES:
@@ -428,12 +464,20 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
             if cls is None:
                 h = np.broadcast_to(h.reshape(_padded(h.shape, len(plan.shape))), plan.shape)
                 cls = (_ffi.FIELD, 0, 0)
-            darr = DeviceArray.from_host(np.ascontiguousarray(h, dtype=plan.dtype), device=dev,
-                                         capacity=_reserved(h.size * plan.dtype.itemsize, reserve_rows))
+            hc = np.ascontiguousarray(h, dtype=plan.dtype)
+            cap = _reserved(hc.size * plan.dtype.itemsize, reserve_rows)
+            if staged and hc.nbytes >= (1 << 20):
+                # streamed path: all host operands of the slice go up as ONE pipelined job through pinned buffers
+                darr = DeviceArray.empty(hc.shape, plan.dtype, dev, capacity=cap)
+                uploads.append((darr.on(stream), hc.ctypes.data, hc.nbytes, hc))
+            else:
+                darr = DeviceArray.from_host(hc, device=dev, capacity=cap)
             temps.append(darr)
         # .on(stream): an input last used on another stream makes this stream wait for that work (device-side)
         operands.append(_ffi.Operand(darr.on(stream), cls[0], 0, cls[1], cls[2]))
 
+    if uploads:
+        _copy_staged(dev, True, [u[:3] for u in uploads], stream)  # returns once the caller's memory has been read
     results = [DeviceArray.empty(plan.shape, plan.dtype, dev, capacity=_reserved(plan.n * plan.dtype.itemsize, reserve_rows))
                for _ in outs]
     cargs = [dev, stream] + [C.byref(o) for o in operands] + [int(v) for v in ints]
@@ -443,7 +487,7 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
     _ffi.check(fn(*cargs))
     pend = _Pending()
     pend.plan, pend.results, pend.temps, pend.host_out = plan, results, temps, host_out
-    pend.internal_out, pend.toucher, pend.stream = internal_out, toucher, stream
+    pend.internal_out, pend.toucher, pend.stream, pend.staged = internal_out, toucher, stream, staged
     return pend
 
 
@@ -461,6 +505,16 @@ def _collect(pend):
     if toucher is not None:
         toucher.join()
     host = []
+    if pend.staged and host_out is not None and all(
+            h.dtype == plan.dtype and h.flags.c_contiguous and h.size == r.size for h, r in zip(host_out, results)):
+        # streamed path: all results of the slice come down as ONE pipelined job through pinned buffers
+        _copy_staged(plan.device, False, [(h.ctypes.data, r.on(pend.stream), r.nbytes) for h, r in zip(host_out, results)],
+                     pend.stream)
+        for r in results:
+            r.free()
+        for t in temps:
+            t.free()
+        return tuple(host_out)
     for k, r in enumerate(results):
         if host_out is not None and host_out[k].dtype == plan.dtype and host_out[k].flags.c_contiguous:
             h = r.to_host(out=host_out[k])  # straight into the caller's slice

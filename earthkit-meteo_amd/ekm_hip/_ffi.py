@@ -55,6 +55,7 @@ def _signatures():
         "ekm_malloc": ([i, sz, pvp], i), "ekm_free": ([i, vp], i),
         "ekm_host_alloc": ([sz, pvp], i), "ekm_host_free": ([vp], i),
         "ekm_host_prefault": ([vp, sz, i], i),
+        "ekm_copy_staged": ([i, i, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), vp, i], i),
         "ekm_host_memcpy": ([vp, vp, sz, i], i), "ekm_host_register": ([vp, sz], i), "ekm_host_unregister": ([vp], i),
         "ekm_h2d": ([i, vp, vp, sz, vp], i), "ekm_d2h": ([i, vp, vp, sz, vp], i),
         "ekm_d2d": ([i, vp, vp, sz, vp], i), "ekm_memset": ([i, vp, i, sz, vp], i),

@@ -29,7 +29,7 @@ def test_plan_fits_the_budget_and_keeps_at_least_two_in_flight(rows, row_bytes, 
 
 
 def test_plan_prefers_many_lanes_when_memory_allows_and_degrades_to_double_buffering():
-    assert plan_slices(137, 225 * MiB, 230_000 * MiB)[0] == 8
+    assert plan_slices(137, 225 * MiB, 230_000 * MiB) == (8, 120)  # fits: 8 lanes, ~256-MiB slices (short ramp)
     lanes, nslices = plan_slices(137, 225 * MiB, 500 * MiB)
     assert lanes == 2 and nslices == 137  # one row per slice, two in flight
     assert plan_slices(137, 225 * MiB, 400 * MiB) is None  # two rows do not fit: the caller raises

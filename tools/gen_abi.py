@@ -181,6 +181,14 @@ EKM_API int ekm_host_alloc(size_t bytes, void** out);  /* pinned host memory for
 EKM_API int ekm_host_free(void* ptr);
 EKM_API int ekm_host_prefault(void* ptr, size_t bytes, int nthreads); /* fault in every page of a host buffer; never changes its contents */
 EKM_API int ekm_host_memcpy(void* dst, const void* src, size_t bytes, int nthreads); /* host-to-host copy on `nthreads` threads (staging through pinned buffers) */
+/* Move `nseg` host<->device segments through a ring of pinned staging buffers with `nthreads` copy threads, as ONE
+ * pipelined job (the NumPy-in / NumPy-out path: pageable caller memory on one side).  to_device = 1: dst[] device,
+ * src[] host; returns once every chunk has been copied out of the caller's memory and its DMA is enqueued on
+ * `stream` (later work on that stream sees the data; the caller's memory may be reused at once).  to_device = 0:
+ * dst[] host, src[] device; the DMAs are enqueued on `stream` (after the work already there) and the call returns
+ * when all data is in the caller's memory.  An upload and a download job may run at the same time (full duplex). */
+EKM_API int ekm_copy_staged(int dev, int to_device, int nseg, void* const* dst, const void* const* src,
+                            const size_t* bytes, void* stream, int nthreads);
 EKM_API int ekm_host_register(void* ptr, size_t bytes);   /* pin caller-owned host memory in place (hipHostRegister) */
 EKM_API int ekm_host_unregister(void* ptr);
 EKM_API int ekm_h2d(int dev, void* dst, const void* src, size_t bytes, void* stream);

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the NumPy-in / NumPy-out path (reported beside, never as, the HBM-resident
-`value`): P3 and theta on an 8-level slab of the benchmark field (8 x 1800 x 3600 fp32 = 207 MB per array),
-pageable host memory, best of 5 calls."""
+`value`): P3, theta and P5 on an 8-level and a 32-level slab of the benchmark field (1800 x 3600 fp32 points per
+level = 26 MB per level and array), pageable host memory, best of 5 calls -- with the transfers staged through the
+library's pinned ring (the default) and as plain pageable hipMemcpyAsync (EKM_STAGED=0, the round-2 path)."""
 import os
 import sys
 import time
@@ -11,21 +12,25 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "earthkit-meteo_amd")]
 import ekm_hip  # noqa: E402
-from ekm_hip import thermo  # noqa: E402
+from ekm_hip import _engine, thermo  # noqa: E402
 from oracle import synthetic  # noqa: E402
 
-t, q, p, _ = synthetic.make_fields(8, 1800 * 3600, dtype=np.float32, seed=3)
-n = t.size
-for name, fn, args, nio in (("pipeline_svp_td_rh", thermo.pipeline_svp_td_rh, (t, q, p), 6),
-                            ("potential_temperature", thermo.potential_temperature, (t, p), 3),
-                            ("pipeline_full", thermo.pipeline_full, (t, q, p), 9)):
-    best, res = 1e9, None
-    for _ in range(5):
-        res = None  # the previous result is released OUTSIDE the timed region (munmap of 600 MB costs ~30 ms by itself)
-        t0 = time.perf_counter()
-        res = fn(*args)
-        best = min(best, time.perf_counter() - t0)
-    res = None
-    print(f"{name:24s} {n} points, {nio} arrays x {t.nbytes / 1e6:.0f} MB over PCIe: {best * 1e3:7.1f} ms per call = "
-          f"{n / best / 1e9:5.2f} G grid-points/s, {nio * t.nbytes / best / 1e9:5.1f} GB/s both directions together")
+for nlev in (8, 32):
+    t, q, p, _ = synthetic.make_fields(nlev, 1800 * 3600, dtype=np.float32, seed=3)
+    n = t.size
+    for staged in (False, True):
+        _engine._STAGED = staged
+        for name, fn, args, nio in (("pipeline_svp_td_rh", thermo.pipeline_svp_td_rh, (t, q, p), 6),
+                                    ("potential_temperature", thermo.potential_temperature, (t, p), 3),
+                                    ("pipeline_full", thermo.pipeline_full, (t, q, p), 9)):
+            best, res = 1e9, None
+            for _ in range(5):
+                res = None  # the previous result is released OUTSIDE the timed region (munmap of 600 MB costs ~30 ms by itself)
+                t0 = time.perf_counter()
+                res = fn(*args)
+                best = min(best, time.perf_counter() - t0)
+            res = None
+            print(f"{'staged  ' if staged else 'pageable'} {name:24s} {nlev:3d} levels, {nio} arrays x {t.nbytes / 1e6:.0f} MB over PCIe: "
+                  f"{best * 1e3:7.1f} ms per call = {n / best / 1e9:5.2f} G grid-points/s, {nio * t.nbytes / best / 1e9:5.1f} GB/s "
+                  f"both directions together", flush=True)
 print(ekm_hip.memory_stats())
