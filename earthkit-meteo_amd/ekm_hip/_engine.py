@@ -170,7 +170,7 @@ def leading_axis_bounds(n0, nshards):
 
 _streams = {}
 _streams_lock = threading.Lock()
-_STAGED = os.environ.get("EKM_STAGED", "1") != "0"  # streamed path: transfers through the pinned staging ring
+_STAGED = os.environ.get("EKM_STAGED", "0") == "1"  # streamed path: transfers through the library's pinned staging ring instead
 _MAX_LANES = 8            # slices in flight per GPU when memory allows (upload of one overlaps download of another)
 _MIN_SLICE_BYTES = 16 << 20  # do not cut finer than this: small copies waste PCIe bandwidth
 _BLOCK_OVERHEAD = (1 << 20) + 16 * (20 << 10)  # worst-case rounding + stagger padding of one device block
@@ -241,6 +241,70 @@ def plan_slices(rows, row_bytes, budget, max_lanes=_MAX_LANES, min_slice=_MIN_SL
     return None
 
 
+_PAGE = 4096
+_PINNED = os.environ.get("EKM_PIN_HOST", "1") != "0"  # streamed path: pin the caller's memory in place, slice by slice
+
+
+class _Pinner:
+    """Pins caller-owned host memory in place (hipHostRegister), one slice ahead of the transfers, and moves data
+    to / from it.
+
+    Measured on the GPU box (tools/host_link_probe.py, profiles/r03_host_link_probe.txt): from pinned memory the
+    link moves 57 GB/s per direction and 96 GB/s in both at once with no host CPU work, and pinning costs 10 ms per
+    GB (105 GB/s) -- faster than the link, so a pinner thread stays ahead of the copies.  A pageable
+    hipMemcpyAsync of a 26-MB slice reaches ~30 GB/s per direction (the runtime pins and unpins around every copy).
+    Only the whole pages INSIDE a slice's byte range are pinned, so the pieces of neighbouring slices never overlap;
+    the two sub-page ends of a range travel as tiny pageable copies.  Pinning also creates the pages of fresh result
+    arrays.  Any registration that fails simply leaves that range pageable: the copies still work."""
+
+    def __init__(self):
+        self.pinned = set()
+        self.lock = threading.Lock()
+
+    @staticmethod
+    def body(ptr, nbytes):
+        lo, hi = -(-ptr // _PAGE) * _PAGE, (ptr + nbytes) // _PAGE * _PAGE
+        return (lo, hi) if hi - lo >= (1 << 20) else None
+
+    def pin(self, ptr, nbytes):
+        b = self.body(ptr, nbytes)
+        if b is not None and _ffi.lib().ekm_host_register(b[0], b[1] - b[0]) >= 0:
+            with self.lock:
+                self.pinned.add(b)
+
+    def unpin(self, ptr, nbytes):
+        b = self.body(ptr, nbytes)
+        with self.lock:
+            if b not in self.pinned:
+                return
+            self.pinned.discard(b)
+        _ffi.lib().ekm_host_unregister(b[0])
+
+    def unpin_all(self):
+        with self.lock:
+            left, self.pinned = list(self.pinned), set()
+        for b in left:
+            _ffi.lib().ekm_host_unregister(b[0])
+
+    def _parts(self, ptr, nbytes):
+        b = self.body(ptr, nbytes)
+        with self.lock:
+            ok = b in self.pinned
+        if not ok:
+            return [(0, nbytes)]
+        return [(o, n) for o, n in ((0, b[0] - ptr), (b[0] - ptr, b[1] - b[0]), (b[1] - ptr, ptr + nbytes - b[1])) if n]
+
+    def h2d(self, dev, dptr, hptr, nbytes, stream):
+        lib = _ffi.lib()
+        for off, n in self._parts(hptr, nbytes):
+            _ffi.check(lib.ekm_h2d(dev, dptr + off, hptr + off, n, stream))
+
+    def d2h(self, dev, hptr, dptr, nbytes, stream):
+        lib = _ffi.lib()
+        for off, n in self._parts(hptr, nbytes):
+            _ffi.check(lib.ekm_d2h(dev, hptr + off, dptr + off, n, stream))
+
+
 def _run_streamed(name, args, ints, eps, dtype, devs):
     """Grid points are independent: cut the broadcast result along its leading axis, give every operand that
     spans that axis the matching slice and every other operand (scalars, trailing-axis vectors) whole, and
@@ -291,15 +355,33 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
         for sl in mine:
             ready[sl] = threading.Event()
 
+    # Pin the caller's arrays and the result arrays in place, slice by slice, ahead of the transfers (a pinner thread,
+    # at most `depth + 2` slices ahead per GPU; a finished slice is unpinned by the downloader).  The operands that
+    # qualify: C-contiguous, already in the compute dtype, spanning the leading axis.
+    pinner = _Pinner() if _PINNED and not _STAGED else None
+    pin_in = [h for h, sp in zip(host, spans) if sp and h.flags.c_contiguous and h.dtype == cdtype] if pinner else []
+    pin_out = outs if pinner and out_dtype == cdtype else []
+    pin_ahead = [threading.Semaphore(depth + 2) for depth, _n in plans]
+
+    def slice_ranges(lo, hi):
+        return [(a[lo:hi].ctypes.data, a[lo:hi].nbytes) for a in pin_in + pin_out]
+
     def toucher():
-        # fault in the result pages slice by slice, in the order the downloads will need them, all GPUs interleaved
+        # make the result pages exist slice by slice, in the order the transfers will need them, all GPUs interleaved:
+        # by pinning them (which also pins the inputs), else by faulting them in
         try:
             lib = _ffi.lib()
             for k in range(max(len(m) for m in slices)):
-                for mine in slices:
+                for d, mine in enumerate(slices):
                     if k < len(mine):
                         lo, hi = mine[k]
-                        if outs[0][lo:hi].nbytes >= _PRETOUCH_BYTES // 8:
+                        if pinner is not None:
+                            pin_ahead[d].acquire()
+                            if errors:
+                                return
+                            for ptr, nb in slice_ranges(lo, hi):
+                                pinner.pin(ptr, nb)
+                        if not pin_out and outs[0][lo:hi].nbytes >= _PRETOUCH_BYTES // 8:
                             for o in outs:
                                 lib.ekm_host_prefault(o[lo:hi].ctypes.data, o[lo:hi].nbytes, 4)
                         ready[mine[k]].set()
@@ -310,7 +392,7 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
     trace = [] if os.environ.get("EKM_TRACE_STREAM") else None
     import time as _time
 
-    def uploader(dev, mine, depth, slots, handoff, most):
+    def uploader(dev, mine, depth, slots, handoff, most, d):
         # ONE host-to-device copy in flight per GPU: concurrent pageable uploads collapse (207 MB in 1 / 2 / 4 / 8
         # threads: 48 / 53 / 19 / 16 GB/s), while an upload and a download run together at full rate (PCIe duplex)
         try:
@@ -320,6 +402,8 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
                 slots.acquire()  # at most `depth` slices resident on the device
                 if errors:
                     break
+                if pinner is not None:
+                    ready[(lo, hi)].wait()  # its host ranges are pinned
                 t1 = _time.perf_counter()
                 set_stream(_lane_stream(dev, k % depth))
                 # operands that span the leading axis get the matching slice; everything else is passed as
@@ -328,7 +412,7 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
                 # slices differ by one row: every slice's device blocks are sized for the LONGEST slice, so a lane takes
                 # back exactly the blocks it released (same bucket) and the footprint stays lanes x slice, live + cached
                 handoff.put(((lo, hi), _submit(name, part, ints, eps, dtype, host_out=[o[lo:hi] for o in outs],
-                                               reserve_rows=(hi - lo, most), staged=_STAGED)))
+                                               reserve_rows=(hi - lo, most), staged=_STAGED, copier=pinner)))
                 if trace is not None:
                     trace.append(("up", k, t0, t1, _time.perf_counter()))
         except BaseException as exc:  # surfaced in the calling thread
@@ -336,7 +420,7 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
         finally:
             handoff.put(None)
 
-    def downloader(dev, slots, handoff):
+    def downloader(dev, slots, handoff, d):
         # ... and ONE device-to-host copy; a collected slice's device blocks go back to the block cache of its
         # stream and are taken again when the uploader comes round to that stream
         try:
@@ -356,6 +440,10 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
                         if trace is not None:
                             trace.append(("down", sl[0], t0, t1, _time.perf_counter()))
                 finally:
+                    if pinner is not None:
+                        for ptr, nb in slice_ranges(*sl):
+                            pinner.unpin(ptr, nb)
+                        pin_ahead[d].release()
                     slots.release()
         except BaseException as exc:
             errors.append(exc)
@@ -363,14 +451,16 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
                 slots.release()
 
     threads = [threading.Thread(target=toucher)]
-    for dev, mine, (depth, _n), most in zip(devs, slices, plans, max_rows):
+    for d, (dev, mine, (depth, _n), most) in enumerate(zip(devs, slices, plans, max_rows)):
         slots, handoff = threading.Semaphore(depth), queue.Queue()
-        threads.append(threading.Thread(target=uploader, args=(dev, mine, depth, slots, handoff, most)))
-        threads.append(threading.Thread(target=downloader, args=(dev, slots, handoff)))
+        threads.append(threading.Thread(target=uploader, args=(dev, mine, depth, slots, handoff, most, d)))
+        threads.append(threading.Thread(target=downloader, args=(dev, slots, handoff, d)))
     for th in threads:
         th.start()
     for th in threads:
         th.join()
+    if pinner is not None:
+        pinner.unpin_all()  # (only after an error: every finished slice has been unpinned already)
     if errors:
         raise errors[0]
     if trace is not None:  # EKM_TRACE_STREAM=1: when each slice waited / moved (ms since the first event)
@@ -383,7 +473,7 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
 class _Pending:
     """One submitted launch: device results (and the temporaries its operands live in) not yet collected."""
 
-    __slots__ = ("plan", "results", "temps", "host_out", "internal_out", "toucher", "stream", "staged")
+    __slots__ = ("plan", "results", "temps", "host_out", "internal_out", "toucher", "stream", "staged", "copier", "keep")
 
 
 def _reserved(nbytes, reserve_rows):
@@ -413,7 +503,8 @@ def _copy_staged(dev, to_device, pairs, stream):
     _ffi.check(_ffi.lib().ekm_copy_staged(dev, int(to_device), n, dst, src, nb, stream, _STAGE_THREADS))
 
 
-def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=None, reserve_rows=None, staged=False):
+def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=None, reserve_rows=None, staged=False,
+            copier=None):
     """Upload what lives on the host, launch, return without waiting for the kernel (the uploads themselves are
     synchronous copies on the current stream).  `reserve_rows` = (rows of this slice, rows of the longest slice):
     field-sized device blocks are reserved at the longest slice's size (streamed path)."""
@@ -428,6 +519,7 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
     temps = []  # device buffers owned by this call
     operands = []
     uploads = []  # staged: (device pointer, host pointer, bytes, the host array kept alive)
+    keep = []     # host arrays an asynchronous upload is still reading
     lds_bytes = 0
     internal_out = False  # host_out allocated here (compute dtype) rather than supplied by the caller
     if not plan.on_device and host_out is None and plan.n * plan.dtype.itemsize >= _PRETOUCH_BYTES:
@@ -466,7 +558,13 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
                 cls = (_ffi.FIELD, 0, 0)
             hc = np.ascontiguousarray(h, dtype=plan.dtype)
             cap = _reserved(hc.size * plan.dtype.itemsize, reserve_rows)
-            if staged and hc.nbytes >= (1 << 20):
+            if copier is not None and hc.nbytes >= (1 << 20):
+                # streamed path, caller memory pinned in place: an asynchronous DMA, ordered before the kernel on this
+                # stream (`hc` is kept alive with the launch until its results have been collected)
+                darr = DeviceArray.empty(hc.shape, plan.dtype, dev, capacity=cap)
+                copier.h2d(dev, darr.on(stream), hc.ctypes.data, hc.nbytes, stream)
+                keep.append(hc)
+            elif staged and hc.nbytes >= (1 << 20):
                 # streamed path: all host operands of the slice go up as ONE pipelined job through pinned buffers
                 darr = DeviceArray.empty(hc.shape, plan.dtype, dev, capacity=cap)
                 uploads.append((darr.on(stream), hc.ctypes.data, hc.nbytes, hc))
@@ -488,6 +586,7 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
     pend = _Pending()
     pend.plan, pend.results, pend.temps, pend.host_out = plan, results, temps, host_out
     pend.internal_out, pend.toucher, pend.stream, pend.staged = internal_out, toucher, stream, staged
+    pend.copier, pend.keep = copier, keep
     return pend
 
 
@@ -505,6 +604,17 @@ def _collect(pend):
     if toucher is not None:
         toucher.join()
     host = []
+    if pend.copier is not None and host_out is not None and all(
+            h.dtype == plan.dtype and h.flags.c_contiguous and h.size == r.size for h, r in zip(host_out, results)):
+        # streamed path, result memory pinned in place: asynchronous DMAs, one wait for the whole slice
+        for h, r in zip(host_out, results):
+            pend.copier.d2h(plan.device, h.ctypes.data, r.on(pend.stream), r.nbytes, pend.stream)
+        _ffi.check(_ffi.lib().ekm_stream_sync(plan.device, pend.stream))
+        for r in results:
+            r.free()
+        for t in temps:
+            t.free()
+        return tuple(host_out)
     if pend.staged and host_out is not None and all(
             h.dtype == plan.dtype and h.flags.c_contiguous and h.size == r.size for h, r in zip(host_out, results)):
         # streamed path: all results of the slice come down as ONE pipelined job through pinned buffers

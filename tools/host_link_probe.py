@@ -113,6 +113,22 @@ def main():
 
         print(f"staged through {ring} pinned chunks of {chunk_mb} MiB, {nt} copy threads per direction: upload alone {rate(up, N):6.1f} GB/s   "
               f"download alone {rate(dn, N):6.1f} GB/s   both at once {rate(both(up, dn), 2 * N):6.1f} GB/s (sum)")
+    # the library's own staged transfer (ekm_copy_staged): one 512-MiB segment, and the same bytes as 20 segments
+    def staged(to_dev, nseg, nt, s):
+        seg = N // nseg
+        if to_dev:
+            dst = (C.c_void_p * nseg)(*[d1 + k * seg for k in range(nseg)])
+            src = (C.c_void_p * nseg)(*[p1 + k * seg for k in range(nseg)])
+        else:
+            dst = (C.c_void_p * nseg)(*[p2 + k * seg for k in range(nseg)])
+            src = (C.c_void_p * nseg)(*[d2 + k * seg for k in range(nseg)])
+        nb = (C.c_size_t * nseg)(*[seg] * nseg)
+        return lambda: (chk(lib.ekm_copy_staged(0, int(to_dev), nseg, dst, src, nb, s, nt)), chk(lib.ekm_stream_sync(0, s)))
+
+    for nseg, nt in ((1, 4), (20, 4), (1, 2), (1, 8)):
+        print(f"ekm_copy_staged {nseg:2d} segment(s), {nt} threads: upload alone {rate(staged(True, nseg, nt, s1), N):6.1f} GB/s   "
+              f"download alone {rate(staged(False, nseg, nt, s2), N):6.1f} GB/s   both at once "
+              f"{rate(both(staged(True, nseg, nt, s1), staged(False, nseg, nt, s2)), 2 * N):6.1f} GB/s (sum)", flush=True)
     t0 = time.perf_counter()
     chk(lib.ekm_host_register(p1, N))
     t1 = time.perf_counter()

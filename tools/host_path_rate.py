@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the NumPy-in / NumPy-out path (reported beside, never as, the HBM-resident
 `value`): P3, theta and P5 on an 8-level and a 32-level slab of the benchmark field (1800 x 3600 fp32 points per
-level = 26 MB per level and array), pageable host memory, best of 5 calls -- with the transfers staged through the
-library's pinned ring (the default) and as plain pageable hipMemcpyAsync (EKM_STAGED=0, the round-2 path)."""
+level = 26 MB per level and array), pageable caller memory, best of 5 calls, by three routes: plain pageable
+hipMemcpyAsync (the round-2 path, EKM_PIN_HOST=0), staged through the library's pinned ring with threaded host copies
+(EKM_STAGED=1), and with the caller's memory pinned in place slice by slice ahead of the transfers (the default)."""
 import os
 import sys
 import time
@@ -18,8 +19,8 @@ from oracle import synthetic  # noqa: E402
 for nlev in (8, 32):
     t, q, p, _ = synthetic.make_fields(nlev, 1800 * 3600, dtype=np.float32, seed=3)
     n = t.size
-    for staged in (False, True):
-        _engine._STAGED = staged
+    for mode in ("pageable", "staged", "pinned"):
+        _engine._STAGED, _engine._PINNED = mode == "staged", mode == "pinned"
         for name, fn, args, nio in (("pipeline_svp_td_rh", thermo.pipeline_svp_td_rh, (t, q, p), 6),
                                     ("potential_temperature", thermo.potential_temperature, (t, p), 3),
                                     ("pipeline_full", thermo.pipeline_full, (t, q, p), 9)):
@@ -30,7 +31,7 @@ for nlev in (8, 32):
                 res = fn(*args)
                 best = min(best, time.perf_counter() - t0)
             res = None
-            print(f"{'staged  ' if staged else 'pageable'} {name:24s} {nlev:3d} levels, {nio} arrays x {t.nbytes / 1e6:.0f} MB over PCIe: "
+            print(f"{mode:8s} {name:24s} {nlev:3d} levels, {nio} arrays x {t.nbytes / 1e6:.0f} MB over PCIe: "
                   f"{best * 1e3:7.1f} ms per call = {n / best / 1e9:5.2f} G grid-points/s, {nio * t.nbytes / best / 1e9:5.1f} GB/s "
                   f"both directions together", flush=True)
 print(ekm_hip.memory_stats())
