@@ -242,7 +242,14 @@ def plan_slices(rows, row_bytes, budget, max_lanes=_MAX_LANES, min_slice=_MIN_SL
 
 
 _PAGE = 4096
-_PINNED = os.environ.get("EKM_PIN_HOST", "1") != "0"  # streamed path: pin the caller's memory in place, slice by slice
+# Streamed path, route of the transfers.  Measured on the GPU box (tools/host_path_rate.py, profiles/r03_host_path_rate.txt;
+# link capacity: tools/host_link_probe.py, profiles/r03_host_link_probe.txt -- 57 GB/s per direction, 96 GB/s both ways):
+#   plain pageable hipMemcpyAsync per operand (default)          P3 on 8 levels 57 GB/s both directions together
+#   EKM_STAGED=1    through the library's pinned ring            50 GB/s (8 host threads busy; a 78-MB job is mostly ramp)
+#   EKM_PIN_HOST=1  caller memory pinned in place, slice-wise    40 GB/s (registering FRESH result pages is slow and
+#                                                                 stalls the DMA queue while it runs)
+# so neither alternative is the default; both stay selectable and tested.
+_PINNED = os.environ.get("EKM_PIN_HOST", "0") == "1"
 
 
 class _Pinner:
