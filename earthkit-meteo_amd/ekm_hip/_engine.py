@@ -133,10 +133,61 @@ class _Plan:
         self.n = int(np.prod(self.shape, dtype=np.int64))
 
 
+_KDLROCM = 10
+
+
+def _adopt_foreign(args):
+    """Arrays of another ROCm library (anything whose `__dlpack_device__()` says kDLROCM: a torch / cupy device
+    tensor) are taken over through DLPack -- zero copy, the producer ordered before our stream -- exactly as if the
+    caller had written `ekm_hip.from_dlpack(x)`: the reference selects its backend from the input type in the same way
+    (`array_namespace(*inputs)`, thermo/array/thermo.py:826, es_comp.py:73).  Returns the arguments with such arrays
+    wrapped, and the name of the producing library when EVERY array argument came from that one library (else None)."""
+    mods, plain, out = set(), False, []
+    for a in args:
+        dd = None
+        if not isinstance(a, (DeviceArray, HybridPressure, np.ndarray, np.generic, bool, int, float, list, tuple)):
+            dd = getattr(a, "__dlpack_device__", None)
+        if dd is not None and hasattr(a, "__dlpack__") and dd()[0] == _KDLROCM:
+            from .dlpack import from_dlpack
+
+            try:
+                out.append(from_dlpack(a))
+            except ValueError:  # not C-contiguous: the producer's own compaction, then zero copy
+                if not hasattr(a, "contiguous"):
+                    raise
+                out.append(from_dlpack(a.contiguous()))
+            mods.add(type(a).__module__.split(".")[0])
+        else:
+            out.append(a)
+            plain = plain or isinstance(a, (DeviceArray, HybridPressure)) or np.ndim(a) > 0
+    return out, (mods.pop() if len(mods) == 1 and not plain else None)
+
+
+def _hand_back(results, module):
+    """Results for a caller whose inputs all came from one foreign library: through that library's own
+    `from_dlpack` (zero copy; it passes its current stream, which is then ordered after our kernel).  The library
+    is looked up among the modules the CALLER has imported -- the product never imports it."""
+    import sys
+
+    fn = getattr(sys.modules.get(module), "from_dlpack", None)
+    if fn is None:
+        return results
+    return tuple(fn(r) if isinstance(r, DeviceArray) else r for r in results)
+
+
 def run(name, args, ints=(), eps=None, dtype=None):
     """Launch entry point `name` on `args`; returns a tuple of outputs.  NumPy inputs that are large
     (>= 256 MB), or any NumPy inputs inside `ekm_hip.multi_gpu()`, are streamed through the GPU(s) in
     slices of their leading axis with a bounded device working set (`_run_streamed`)."""
+    from .device import current_devices
+
+    args, foreign = _adopt_foreign(args)
+    if foreign is not None:
+        return _hand_back(_run(name, args, ints, eps, dtype), foreign)
+    return _run(name, args, ints, eps, dtype)
+
+
+def _run(name, args, ints, eps, dtype):
     from .device import current_devices
 
     devs = current_devices()

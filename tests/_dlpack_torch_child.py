@@ -44,6 +44,28 @@ doubled = (back * 2.0).cpu().numpy()
 assert np.array_equal(back.cpu().numpy(), want, equal_nan=True), "kernel on torch memory differs from our own path"
 assert np.array_equal(doubled, want * 2.0, equal_nan=True)
 
+# IMPLICIT: torch tensors straight into the thermo functions (the reference's array_namespace(*inputs) dispatch,
+# thermo/array/thermo.py:826): taken over through DLPack, and -- every array input being torch's -- handed back as a
+# torch tensor on the same device: zero copy both ways, stream-ordered, the bits of the DeviceArray path
+with torch.cuda.stream(side):
+    ut, uq, up = tt * 1.0, tq * 1.0, tp * 1.0   # still in flight on torch's side stream at the call
+    out = ek.thermo.relative_humidity_from_specific_humidity(ut, uq, up)
+    assert isinstance(out, torch.Tensor) and out.device == ut.device and out.dtype == torch.float32 and tuple(out.shape) == t.shape
+    assert np.array_equal(out.cpu().numpy(), want, equal_nan=True), "implicit torch path differs from the DeviceArray path"
+    es_, td_, rh_ = ek.thermo.pipeline_svp_td_rh(ut, uq, up)
+    assert all(isinstance(x, torch.Tensor) for x in (es_, td_, rh_)) and np.array_equal(rh_.cpu().numpy(), want, equal_nan=True)
+    mixed = ek.thermo.potential_temperature(ut, 85000.0)           # Python scalars do not change whose call it is
+    assert isinstance(mixed, torch.Tensor)
+    plain = ek.thermo.potential_temperature(ut, d[2])               # a DeviceArray among the inputs: DeviceArray out
+    assert isinstance(plain, ek.DeviceArray)
+    strided = ek.thermo.saturation_vapour_pressure(ut.t())          # not C-contiguous: the producer compacts it
+    assert isinstance(strided, torch.Tensor) and tuple(strided.shape) == tuple(ut.t().shape)
+    assert np.array_equal(strided.cpu().numpy(), ek.thermo.saturation_vapour_pressure(np.ascontiguousarray(t.T)), equal_nan=True)
+    host_t = ek.thermo.potential_temperature(torch.from_numpy(t), torch.from_numpy(p))   # CPU tensors: NumPy semantics
+    assert isinstance(host_t, np.ndarray)
+    del out, es_, td_, rh_, mixed, plain, strided
+torch.cuda.synchronize()
+
 # a second round on our own non-default stream: producer is handed that stream
 s1 = ek.stream_create()
 ek.set_stream(s1)
