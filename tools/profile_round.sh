@@ -16,13 +16,18 @@ run full            full:field:f32:137
 run p3              p3:field:f32:137            --workload p3
 run wetbulb         wetbulb:field:f32:137       --workload wetbulb
 run bisect          wetbulb_bisect:field:f32:137 --workload wetbulb_bisect
+run bisect_bolton35 wetbulb_bisect_bolton35:field:f32:137 --workload wetbulb_bisect_bolton35
 run full_level      full:level:f32:137          --pmode level
+run full_hybrid     full:hybrid:f32:137         --pmode hybrid
 run p3_level        p3:level:f32:137            --workload p3 --pmode level
 run p3_hybrid       p3:hybrid:f32:137           --workload p3 --pmode hybrid
+run wetbulb_hybrid  wetbulb:hybrid:f32:137      --workload wetbulb --pmode hybrid
 run theta_hybrid    theta:hybrid:f32:137        --workload theta --pmode hybrid
 run geopotential    geopotential:hybrid:f32:137 --workload geopotential
-for wl in full wetbulb wetbulb_bisect p3; do
+for wl in full wetbulb wetbulb_bisect wetbulb_bisect_bolton35 wetbulb_bisect_bolton39 p3; do
   tools/profile_valu.sh "$G/valu_$wl" --workload $wl > "$G/valu_$wl.log" 2>&1 && python3 tools/summarize_valu.py "$G/valu_$wl" $wl "profiles/${R}_valu_counters.json"
 done
-tools/profile_valu.sh "$G/valu_wetbulb_level" --workload wetbulb --pmode level > /dev/null 2>&1 && python3 tools/summarize_valu.py "$G/valu_wetbulb_level" wetbulb_level "profiles/${R}_valu_counters.json"
-mkdir -p gpurun_out/profiles_$R && cp profiles/${R}_* profiles/traffic_latest.json gpurun_out/profiles_$R/
+for wl in wetbulb wetbulb_bisect; do
+  tools/profile_valu.sh "$G/valu_${wl}_level" --workload $wl --pmode level > /dev/null 2>&1 && python3 tools/summarize_valu.py "$G/valu_${wl}_level" ${wl}@level "profiles/${R}_valu_counters.json"
+done
+mkdir -p gpurun_out/profiles_$R && cp profiles/${R}_* profiles/traffic_latest.json profiles/valu_latest.json gpurun_out/profiles_$R/

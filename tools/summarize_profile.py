@@ -48,9 +48,15 @@ def main():
                                "FETCH_SIZE_KiB_avg": fetch.get(name), "WRITE_SIZE_KiB_avg": write.get(name),
                                "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr, "hbm_bytes_per_launch": rd + wr,
                                "GBps_from_pmc_and_avg_ns": (rd + wr) / float(r["AverageNs"])})
-    if out["kernels"]:  # the benchmarked kernel is the one with the most accumulated time
+    if out["kernels"]:  # the benchmarked kernel is the one with the most accumulated time ...
         main_k = max(out["kernels"], key=lambda k: k["calls"] * k["avg_ns"])
-        traffic[key] = main_k["hbm_bytes_per_launch"]
+        # ... plus, on hybrid levels, its sibling launch (pure pressure levels / hybrid levels: two launches per step)
+        group = [k for k in out["kernels"] if k["calls"] == main_k["calls"] and "map_levels" in k["name"]
+                 and "map_levels" in main_k["name"] and k["name"].split("<")[1].split(",")[0] == main_k["name"].split("<")[1].split(",")[0]]
+        group = group or [main_k]
+        traffic[key] = sum(k["hbm_bytes_per_launch"] for k in group)
+        out["step"] = {"kernels_per_step": len(group), "hbm_bytes_per_step": traffic[key],
+                       "avg_ns_per_step": sum(k["avg_ns"] for k in group)}
     json.dump(out, open(dst + "_summary.json", "w"), indent=1)
     lat = os.path.join(os.path.dirname(dst), "traffic_latest.json")
     cur = json.load(open(lat)) if os.path.exists(lat) else {}

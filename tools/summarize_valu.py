@@ -33,6 +33,22 @@ def main():
     cur = json.load(open(dst)) if os.path.exists(dst) else {}
     cur[key] = out
     json.dump(cur, open(dst, "w"), indent=1)
+    # what bench.py quotes the VALU roof from (profiles/valu_latest.json).  One issue unit = one plain VALU wave
+    # instruction at the rate the microbenchmark sustains (tools/microbench/valu_rates.hip, profiles/r03_valu_microbench.txt:
+    # v_fma_f32 935.4 G wave-instr/s x 64 lanes = 5.99e13 lane-ops/s); a transcendental (v_exp/v_log/v_rcp_f32: 295.2 G
+    # wave-instr/s) occupies the same issue port 3.17 x as long.
+    args = bench["config"]
+    bkey = f"{key.split('@')[0]}:{args['p_mode']}:{bench['dtype']}"
+    lat = os.path.join(os.path.dirname(dst), "valu_latest.json")
+    v = json.load(open(lat)) if os.path.exists(lat) else {}
+    v.setdefault("units_per_point", {})
+    v.update(peak_issue_units_per_s=5.99e13, trans_cost_units=3.17,
+             source="issue units per point = (SQ_INSTS_VALU - SQ_INSTS_VALU_TRANS_F32) + 3.17 x SQ_INSTS_VALU_TRANS_F32 per point from a "
+                    "rocprofv3 --pmc pass of this command (tools/profile_valu.sh); peak = the plain-VALU issue rate of "
+                    "tools/microbench/valu_rates.hip on this part (profiles/r03_valu_microbench.txt: 935.4 G wave-instr/s x 64 lanes), "
+                    "a transcendental costing 3.17 plain instructions (295.2 G wave-instr/s)")
+    v["units_per_point"][bkey] = round((valu - trans) + 3.17 * trans, 2)
+    json.dump(v, open(lat, "w"), indent=1)
     print(key, json.dumps({k: v for k, v in out.items() if k != "raw"}))
 
 
