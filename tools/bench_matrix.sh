@@ -8,6 +8,9 @@ for wl in full p3 wetbulb wetbulb_bisect theta rh ept; do
     timeout -k 10 120 python3 bench.py --workload $wl --pmode $pm --steps 20 --warmup 5 --no-cpu-baseline "$@" >> "$OUT" 2>> "$OUT.err" || echo "{\"failed\": \"$wl $pm\"}" >> "$OUT"
   done
 done
+for wl in wetbulb_bisect_bolton35 wetbulb_bisect_bolton39; do
+  timeout -k 10 120 python3 bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline "$@" >> "$OUT" 2>> "$OUT.err" || echo "{\"failed\": \"$wl\"}" >> "$OUT"
+done
 timeout -k 10 120 python3 bench.py --workload svp --steps 20 --warmup 5 --no-cpu-baseline "$@" >> "$OUT" 2>> "$OUT.err"
 timeout -k 10 120 python3 bench.py --workload hybrid_levels --steps 20 --warmup 5 "$@" >> "$OUT" 2>> "$OUT.err"
 timeout -k 10 120 python3 bench.py --workload geopotential --steps 20 --warmup 5 "$@" >> "$OUT" 2>> "$OUT.err"
@@ -18,7 +21,8 @@ for ln in open(sys.argv[1]):
     if "failed" in d:
         print("FAILED", d["failed"]); continue
     r, c = d["roofline"], d["config"]
-    print(f"{r['kernel'][:44]:44s} {c['p_mode']:6s} {d['dtype']} {r['bytes_per_point']:3d} B/pt  {r['kernel_ms']:7.3f} ms  "
-          f"{r['achieved']:7.1f} GB/s  frac {r['frac']:.3f}  parity {d['parity']['ok'] if d['parity'] else None} "
+    hbm = r.get("hbm_achieved_gbs", r["achieved"])
+    print(f"{c['workload'].split(' on ')[0][:44]:44s} {c['p_mode']:6s} {d['dtype']} {r['bytes_per_point']:3d} B/pt  {r['kernel_ms']:7.3f} ms  "
+          f"{hbm:7.1f} GB/s  hbm frac {r.get('hbm_frac', r['frac']):.3f}  " + (f"valu frac {r['frac']:.3f}  " if r["bound"] == "valu" else "") + f"parity {d['parity']['ok'] if d['parity'] else None} "
           f"maxrel {d['parity']['max_rel_err'] if d['parity'] else None}")
 PY
