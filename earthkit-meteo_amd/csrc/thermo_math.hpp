@@ -175,7 +175,38 @@ EKM_HD double m_exp2(double x) {
   const double r = __builtin_amdgcn_ldexp(p, (int)n);
   return x != x ? x : r;
 }
+// log2 by table: x = mant * 2^e, mant in [0.5, 1); j = the top 6 fraction bits of mant; c_j = 1/(1 + (j + 0.5)/64), so
+// r = 2*mant*c_j - 1 lies in (-1/129, 1/129) (one fma, exact) and log2(x) = (e - 1) - log2(c_j) + log2(1 + r) with a
+// degree-5 polynomial (truncation 5e-14 absolute).  The 1-KiB table is read-only device memory (gen/f64_log2_table.inc):
+// the lanes of a wave touch at most 8 cache lines of it, served by the vector L1 beside the VALU work.  Against the
+// polynomial version below this drops the software reciprocal (v_rcp_f64 + a Newton step, ~35 clocks) of the atanh
+// argument: ~55 instead of ~110 clocks per logarithm.
+#if !defined(EKM_F64_LOG_POLY)
+static __device__ const double kLog2Tab[64][2] = {
+#include "gen/f64_log2_table.inc"
+};
+EKM_HD double m_log2_poly(double x);
 EKM_HD double m_log2(double x) {
+  const double mant = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  const int e = __builtin_amdgcn_frexp_exp(x);
+  const int j = (__double2hiint(mant) >> 14) & 63;
+  const double c2 = kLog2Tab[j][0], lj = kLog2Tab[j][1];
+  const double r = __builtin_fma(mant, c2, -1.0);
+  double p = 0.2 * 1.44269504088896340736;              // log2(1 + r)/r = (1 - r/2 + r^2/3 - r^3/4 + r^4/5)/ln 2
+  p = __builtin_fma(p, r, -0.25 * 1.44269504088896340736);
+  p = __builtin_fma(p, r, (1.0 / 3.0) * 1.44269504088896340736);
+  p = __builtin_fma(p, r, -0.5 * 1.44269504088896340736);
+  p = __builtin_fma(p, r, 1.44269504088896340736);
+  double res = __builtin_fma(p, r, lj + (double)(e - 1));
+  if (x == 0.0) res = -__builtin_inf();
+  if (x == __builtin_inf()) res = x;
+  if (x < 0.0 || x != x) res = __builtin_nan("");
+  return res;
+}
+EKM_HD double m_log2_poly(double x) {
+#else
+EKM_HD double m_log2(double x) {
+#endif
 #if defined(EKM_F64_LOG_SPLIT_SELECT)
   int e = __builtin_amdgcn_frexp_exp(x);
   double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
@@ -603,9 +634,9 @@ template <int METHOD>
 struct BisectEntry<METHOD, double> {
   static constexpr int width = 1;
   EKM_HD static void fill(double* __restrict__ tab, int m) { tab[m] = es_mixed(bisect_lattice_t<double>(m)); }
-  EKM_HD static void load(const double* __restrict__ tab, int m, double t, double& es, double& a) {
+  EKM_HD static void load(const double* __restrict__ tab, int m, double, double& es, double& a) {
     es = tab[m];
-    a = bisect_second<METHOD>(es, m_rcp(t));
+    a = 0.0;  // fp64 forms the t-only factor in the step itself, from the ONE reciprocal it takes (1/(v*t))
   }
 };
 
@@ -639,11 +670,19 @@ EKM_HD T t_on_ma_bisect_tab(T e, T p, const T* __restrict__ tab) {
     T es, a, g;
     BisectEntry<METHOD, T>::load(tab, m, t, es, a);
     esmax = m_max(esmax, es);
+    const T v = METHOD == EPT_IFS ? p + T(k::eps - 1) * es : p - es;
+    T rv;  // 1/v
+    if (BisectEntry<METHOD, T>::width == 2) {
+      rv = m_rcp(v);
+    } else {  // no tabulated a_m: 1/(v*t) gives both 1/v and 1/t (a software reciprocal costs ~35 clocks in fp64)
+      const T r = m_rcp(v * t);
+      rv = r * t;
+      a = bisect_second<METHOD>(es, r * v);
+    }
     if (METHOD == EPT_IFS) {
-      g = a * m_rcp(p + T(k::eps - 1) * es);  // log2 of exp(-K0*qs/t)
+      g = a * rv;  // log2 of exp(-K0*qs/t)
     } else {
-      const T v = p - es;
-      const T ws = T(k::eps) * es * m_rcp(v);
+      const T ws = T(k::eps) * es * rv;
       if (METHOD == EPT_BOLTON35)
         g = kl + ws * (a - T(0.28) * kl);
       else
