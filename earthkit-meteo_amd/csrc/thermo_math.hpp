@@ -175,13 +175,15 @@ EKM_HD double m_exp2(double x) {
   const double r = __builtin_amdgcn_ldexp(p, (int)n);
   return x != x ? x : r;
 }
-// log2 by table: x = mant * 2^e, mant in [0.5, 1); j = the top 6 fraction bits of mant; c_j = 1/(1 + (j + 0.5)/64), so
-// r = 2*mant*c_j - 1 lies in (-1/129, 1/129) (one fma, exact) and log2(x) = (e - 1) - log2(c_j) + log2(1 + r) with a
-// degree-5 polynomial (truncation 5e-14 absolute).  The 1-KiB table is read-only device memory (gen/f64_log2_table.inc):
-// the lanes of a wave touch at most 8 cache lines of it, served by the vector L1 beside the VALU work.  Against the
-// polynomial version below this drops the software reciprocal (v_rcp_f64 + a Newton step, ~35 clocks) of the atanh
-// argument: ~55 instead of ~110 clocks per logarithm.
-#if !defined(EKM_F64_LOG_POLY)
+// -DEKM_F64_LOG_TABLE: log2 by table: x = mant * 2^e, mant in [0.5, 1); j = the top 6 fraction bits of mant;
+// c_j = 1/(1 + (j + 0.5)/64), so r = 2*mant*c_j - 1 lies in (-1/129, 1/129) (one fma, exact) and
+// log2(x) = (e - 1) - log2(c_j) + log2(1 + r) with a degree-5 polynomial (truncation 5e-14 absolute); the 1-KiB table is
+// read-only device memory (gen/f64_log2_table.inc).  It drops the software reciprocal of the atanh argument (~55 instead
+// of ~110 clocks per logarithm) -- and measured in one process against the polynomial version (profiles/
+// r03_sweep_f64_log2_table.txt) it is NOT the default: the table reads go through the same vector-memory path as the
+// streams, so the HBM-bound kernels lose more (theta 3.39 -> 3.53 ms, theta_e 5.25 -> 5.58, the six-output pipeline
+// 16.7 -> 17.3) than the VALU-bound ones gain (wet-bulb 12.33 -> 12.19, bisection 15.9 -> 15.7).
+#if defined(EKM_F64_LOG_TABLE)
 static __device__ const double kLog2Tab[64][2] = {
 #include "gen/f64_log2_table.inc"
 };
