@@ -77,6 +77,10 @@ def parse():
                          "measurement); without it such a run reports value null and oversubscribed true")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise rendezvous/sharding/reporting without touching a GPU (CI on CPU); value is null")
+    ap.add_argument("--traffic", default="measure", choices=["measure", "file", "none"],
+                    help="roofline.traffic: 'measure' = two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of a short run of this "
+                         "same command as child processes after the timed region (N = 1 only; falls back to 'file' if the "
+                         "profiler is unavailable); 'file' = the committed profiles/traffic_latest.json; 'none' = null")
     ap.add_argument("--tiles", type=int, default=0)
     ap.add_argument("--unroll", type=int, default=0)
     return ap.parse_args()
@@ -423,13 +427,18 @@ def main():
         if oversub and not args.allow_shared_device:
             value = None  # ranks shared a GPU: whatever this is, it is not the N-GPU rate
         roof = None
+        traffic, traffic_source = None, "not collected (--traffic none)"
+        if kernel_ms and args.traffic == "measure" and dist.world == 1:
+            traffic, traffic_source = measure_traffic(args, entry)
+        if kernel_ms and traffic is None and args.traffic != "none":
+            why = "" if args.traffic == "file" else f" ({traffic_source})"
+            traffic = traffic_from_profiles(args, n_local)
+            traffic_source = ("profiles/traffic_latest.json: FETCH_SIZE x 2 (gfx950) + WRITE_SIZE from separate rocprofv3 --pmc passes "
+                              "of this command (tools/profile_gpu.sh), committed; not re-measured in this run" + why)
         if kernel_ms:
             achieved = bpp * n_local / (kernel_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles(args, n_local),
-                    "traffic_source": "profiles/traffic_latest.json: FETCH_SIZE x 2 (gfx950) + WRITE_SIZE from separate "
-                                      "rocprofv3 --pmc passes of this command (tools/profile_gpu.sh), committed; "
-                                      "not re-measured in this run",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": entry, "bytes_per_point": bpp, "points_per_launch": n_local,
                     "kernel_ms": round(kernel_ms, 4),
                     "kernel_ms_median": round(float(np.median(per_launch)), 4),
@@ -568,6 +577,55 @@ def valu_from_profiles(args):
         return {"units_per_point": units, "peak": d["peak_issue_units_per_s"], "source": d["source"]}
     except Exception:
         return None
+
+
+def measure_traffic(args, entry):
+    """HBM bytes per step of THIS workload, measured now: two child runs of this script (3 timed steps each) under
+    `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` -- separate passes, the program
+    itself right after `--`, as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- summed over the map kernels of one
+    step.  gfx950 corrections (same guide): the counters are in KiB, and FETCH_SIZE reports half of a 16-B-per-lane
+    streaming read.  Returns (bytes per step, description) or (None, why not)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    steps, warm = 3, 1
+    tmp = tempfile.mkdtemp(prefix="ekm_pmc_", dir="/tmp")
+    per_kernel = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--traffic", "none",
+                   "--workload", args.workload, "--pmode", args.pmode, "--dtype", args.dtype, "--levels", str(args.levels)]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            agg = collections.defaultdict(list)
+            for path in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if row["Counter_Name"] == counter:
+                        agg[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+            per_kernel[counter] = {k: v for k, v in agg.items() if any(t in k for t in ("map_", "geopotential_columns", "hybrid_levels"))}
+        # the kernels of the timed step: launched warm-up + steps times (fill / table kernels run once)
+        total = 0.0
+        for counter, scale in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
+            ks = {k: v for k, v in per_kernel[counter].items() if len(v) == steps + warm}
+            if not ks:
+                return None, f"no kernel with {steps + warm} launches in the {counter} pass"
+            total += scale * sum(sum(v) / len(v) for v in ks.values())
+        return total, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child passes of this command, "
+                       f"{steps} steps each), KiB x 1024, FETCH_SIZE x 2 (gfx950: half of a 16-B/lane streaming read is reported), "
+                       "summed over the kernels of one step")
+    except Exception as exc:  # the profiler must never take the benchmark down
+        return None, f"traffic measurement failed: {type(exc).__name__}: {exc}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def traffic_from_profiles(args, n_local):
