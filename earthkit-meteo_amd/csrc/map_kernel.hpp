@@ -649,7 +649,13 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
     if (most < 1) most = 1;
     tiles = (unsigned)(most < (unsigned long long)tuning_table_tiles() ? most : (unsigned long long)tuning_table_tiles());
   }
-  const int unroll = tuning_unroll();
+  int unroll = tuning_unroll();
+  // the VALU-bound Newton kernels (one output, regime tie inside) hide their loads better with the next tile's loads
+  // issued ahead: two tiles per workgroup, both in flight (3.45 -> 3.41 ms; the HBM-bound kernels prefer one-shot tiles)
+  if (OpUsesTie<Op>::value && NOUT == 1 && sizeof(T) == 4 && !bc && aligned && tiles == 1 && unroll == 1 && ntile >= 4096) {
+    tiles = 2;
+    unroll = 2;
+  }
   if (!bc && aligned && unroll >= 2) tiles = (tiles + 1u) & ~1u;  // the unrolled body takes tiles in pairs
   // keep the grid within the launch limit for very large fields
   while ((ntile + tiles - 1) / tiles > 0x7fffffffull) tiles *= 2;

@@ -461,8 +461,8 @@ EKM_HD T virtual_t(T t, T q) {  // thermo.py:738-764
 
 template <int METHOD, class T>
 EKM_HD T lcl_t(T t, T td) {  // thermo.py:923-968
-  if (METHOD == LCL_DAVIES)
-    return td - (T(0.212) + T(1.571e-3) * (td - T(k::T0)) - T(4.36e-4) * (t - T(k::T0))) * (t - td);
+  if (METHOD == LCL_DAVIES)  // the two "- T0" of the reference's bracket folded into its constant: two fma
+    return td - (T(0.212 - (1.571e-3 - 4.36e-4) * k::T0) + T(1.571e-3) * td - T(4.36e-4) * t) * (t - td);
   return T(56.0) + m_rcp(m_rcp(td - T(56)) + m_log(m_div(t, td)) * T(1.0 / 800));
 }
 
