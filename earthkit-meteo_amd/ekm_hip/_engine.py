@@ -196,9 +196,10 @@ def _run(name, args, ints, eps, dtype):
         # a DeviceArray lives on ONE GPU: computing on it inside multi_gpu() would silently use that single device
         where = sorted({a.device for a in args if isinstance(a, DeviceArray)}
                        | {a.sp.device for a in args if isinstance(a, HybridPressure) and isinstance(a.sp, DeviceArray)})
-        raise _ffi.EkmError(f"{name}: inside ekm_hip.multi_gpu(devices={list(devs)}) the inputs must be host (NumPy) arrays, which "
-                            f"are sharded across the GPUs; these are device-resident on GPU {where} -- call it outside the "
-                            f"block, or shard by hand with ekm_hip.shard_bounds and one DeviceArray per device")
+        if where:
+            raise _ffi.EkmError(f"{name}: inside ekm_hip.multi_gpu(devices={list(devs)}) the inputs must be host (NumPy) arrays, which "
+                                f"are sharded across the GPUs; these are device-resident on GPU {where} -- call it outside the "
+                                f"block, or shard by hand with ekm_hip.shard_bounds and one DeviceArray per device")
     if numpy_only:
         multi = bool(devs) and len(devs) > 1
         if multi or sum(np.asarray(a).nbytes for a in args if np.ndim(a) > 0) >= _STREAM_BYTES:
@@ -299,7 +300,8 @@ _PAGE = 4096
 #   EKM_STAGED=1    through the library's pinned ring            50 GB/s (8 host threads busy; a 78-MB job is mostly ramp)
 #   EKM_PIN_HOST=1  caller memory pinned in place, slice-wise    40 GB/s (registering FRESH result pages is slow and
 #                                                                 stalls the DMA queue while it runs)
-# so neither alternative is the default; both stay selectable and tested.
+#   both            inputs pinned in place, results through the ring   43-54 GB/s
+# so no alternative is the default; they stay selectable and tested.
 _PINNED = os.environ.get("EKM_PIN_HOST", "0") == "1"
 
 
@@ -416,9 +418,9 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
     # Pin the caller's arrays and the result arrays in place, slice by slice, ahead of the transfers (a pinner thread,
     # at most `depth + 2` slices ahead per GPU; a finished slice is unpinned by the downloader).  The operands that
     # qualify: C-contiguous, already in the compute dtype, spanning the leading axis.
-    pinner = _Pinner() if _PINNED and not _STAGED else None
+    pinner = _Pinner() if _PINNED else None  # with _STAGED too: inputs pinned in place, results through the staging ring
     pin_in = [h for h, sp in zip(host, spans) if sp and h.flags.c_contiguous and h.dtype == cdtype] if pinner else []
-    pin_out = outs if pinner and out_dtype == cdtype else []
+    pin_out = outs if pinner and out_dtype == cdtype and not _STAGED else []
     pin_ahead = [threading.Semaphore(depth + 2) for depth, _n in plans]
 
     def slice_ranges(lo, hi):
@@ -662,7 +664,7 @@ def _collect(pend):
     if toucher is not None:
         toucher.join()
     host = []
-    if pend.copier is not None and host_out is not None and all(
+    if pend.copier is not None and not pend.staged and host_out is not None and all(
             h.dtype == plan.dtype and h.flags.c_contiguous and h.size == r.size for h, r in zip(host_out, results)):
         # streamed path, result memory pinned in place: asynchronous DMAs, one wait for the whole slice
         for h, r in zip(host_out, results):

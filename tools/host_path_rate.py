@@ -19,8 +19,8 @@ from oracle import synthetic  # noqa: E402
 for nlev in (8, 32):
     t, q, p, _ = synthetic.make_fields(nlev, 1800 * 3600, dtype=np.float32, seed=3)
     n = t.size
-    for mode in ("pageable", "staged", "pinned"):
-        _engine._STAGED, _engine._PINNED = mode == "staged", mode == "pinned"
+    for mode in ("pageable", "staged", "pinned", "mixed"):  # mixed: inputs pinned in place, results through the ring
+        _engine._STAGED, _engine._PINNED = mode in ("staged", "mixed"), mode in ("pinned", "mixed")
         for name, fn, args, nio in (("pipeline_svp_td_rh", thermo.pipeline_svp_td_rh, (t, q, p), 6),
                                     ("potential_temperature", thermo.potential_temperature, (t, p), 3),
                                     ("pipeline_full", thermo.pipeline_full, (t, q, p), 9)):
