@@ -252,6 +252,30 @@ def test_bench_two_ranks_strong_scaling_on_one_device(ek):
     assert all(x["hip_device_count"] >= 1 for x in ranks)
 
 
+def test_bench_measures_its_hbm_traffic_in_the_run(ek):
+    """bench.py's roofline.traffic comes from two rocprofv3 --pmc child passes of the same command made after the timed
+    region (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE): on 16 levels of the field it must equal the algorithmic 36 B per
+    point within 1 %.  Where the profiler is not available the line says so and falls back to the committed file."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--levels", "16", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    roof = d["roofline"]
+    assert d["parity"]["ok"] and roof["bound"] == "hbm" and d["oversubscribed"] is False
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 not on PATH: " + roof["traffic_source"][:80])
+    assert roof["traffic_source"].startswith("measured in this run"), roof["traffic_source"]
+    algorithmic = roof["bytes_per_point"] * roof["points_per_launch"]
+    print(f"traffic {roof['traffic']:.4g} B vs algorithmic {algorithmic:.4g} B")
+    assert abs(roof["traffic"] / algorithmic - 1.0) < 0.01
+
+
 def test_concurrent_calls_from_several_threads(ek):
     """The reference's functions are stateless and may be called from several threads; here every thread shares the
     block cache, the default stream and the library's device table.  Results must equal the serial ones."""
