@@ -104,6 +104,41 @@ def test_hybrid_pressure_operand(ek, tag, dt):
         ek.thermo.potential_temperature(t[:5], hp)
 
 
+def test_hybrid_pressure_with_non_finite_surface_pressure(ek):
+    """The pure pressure levels of a hybrid table (B = 0) run as a level-vector launch that does not need sp -- but the
+    reference's p = A + B*sp is NaN there for a NaN or infinite sp (0*inf), and so must ours be, on every level, for
+    exactly those columns (aligned and ragged shapes; the all-B-zero sub-table too)."""
+    from oracle import thermo_oracle as orc, vertical_oracle as vo
+
+    A, B = ek.vertical.hybrid_level_parameters(137)
+    rng = np.random.default_rng(4)
+    for npts, sub in ((4096, slice(0, 138)), (1031, slice(0, 138)), (2048, slice(0, 40)), (2048, slice(60, 138))):
+        a_, b_ = A[sub], B[sub]
+        nlev = a_.size - 1
+        sp = rng.uniform(5.2e4, 1.04e5, npts).astype(np.float32)
+        bad = rng.choice(npts, 7, replace=False)
+        sp[bad[:3]], sp[bad[3:5]], sp[bad[5:]] = np.nan, np.inf, -np.inf
+        pfull = vo.pressure_on_hybrid_levels(a_.astype(np.float32), b_.astype(np.float32), sp)
+        t = rng.uniform(200.0, 300.0, (nlev, npts)).astype(np.float32)
+        q = rng.uniform(1e-6, 5e-3, (nlev, npts)).astype(np.float32)
+        hp = ek.HybridPressure(a_, b_, sp)
+        flat = 0
+        while flat < nlev and b_[flat] == 0 and b_[flat + 1] == 0:
+            flat += 1
+        assert hp.nflat == flat and flat == {0: min(53, nlev), 60: 0}[sub.start]
+        for func, args in (("potential_temperature", (t,)), ("pipeline_svp_td_rh", (t, q)),
+                           ("wet_bulb_temperature_from_specific_humidity", (t, q))):
+            got = getattr(ek.thermo, func)(*args, hp)
+            want = getattr(orc, func)(*args, pfull)
+            got = got if isinstance(got, tuple) else (got,)
+            want = want if isinstance(want, tuple) else (want,)
+            for k, (g_, w_) in enumerate(zip(got, want)):
+                if func == "pipeline_svp_td_rh" and k == 0:
+                    continue  # es depends on t alone
+                assert np.array_equal(np.isnan(g_), np.isnan(w_)), (func, npts, sub, k)
+                assert np.isnan(g_[:, bad]).all() and np.isfinite(g_[:, np.setdiff1d(np.arange(npts), bad)][nlev // 2:]).all()
+
+
 from test_vertical_oracle import CHAIN, chain_args, chain_calls  # noqa: E402
 
 
