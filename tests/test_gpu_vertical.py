@@ -126,10 +126,14 @@ def test_hybrid_pressure_with_non_finite_surface_pressure(ek):
         while flat < nlev and b_[flat] == 0 and b_[flat + 1] == 0:
             flat += 1
         assert hp.nflat == flat and flat == {0: min(53, nlev), 60: 0}[sub.start]
-        for func, args in (("potential_temperature", (t,)), ("pipeline_svp_td_rh", (t, q)),
-                           ("wet_bulb_temperature_from_specific_humidity", (t, q))):
-            got = getattr(ek.thermo, func)(*args, hp)
-            want = getattr(orc, func)(*args, pfull)
+        for func, args, kw in (("potential_temperature", (t,), {}), ("pipeline_svp_td_rh", (t, q), {}),
+                               ("wet_bulb_temperature_from_specific_humidity", (t, q), {"t_method": "newton"}),
+                               ("wet_bulb_temperature_from_specific_humidity", (t, q), {"t_method": "bisect"})):
+            got = getattr(ek.thermo, func)(*args, hp, **kw)
+            if kw.get("t_method") == "bisect":  # the reference's bisection takes 1-D input only
+                want = getattr(orc, func)(*(a.ravel() for a in args), pfull.ravel(), **kw).reshape(pfull.shape)
+            else:
+                want = getattr(orc, func)(*args, pfull, **kw)
             got = got if isinstance(got, tuple) else (got,)
             want = want if isinstance(want, tuple) else (want,)
             for k, (g_, w_) in enumerate(zip(got, want)):
