@@ -18,6 +18,38 @@ _F32, _F64 = np.dtype(np.float32), np.dtype(np.float64)
 PRESSURE_TOA = 0.1  # vertical.py:674
 
 
+def _foreign_aware(*names):
+    """Arguments `names` of the wrapped function may be arrays of another ROCm library (torch / cupy device tensors:
+    `__dlpack_device__()` says kDLROCM): they are taken over through DLPack exactly as in ekm_hip.thermo
+    (`_engine._adopt_foreign`), and when every such argument came from one library the DeviceArray results go back
+    through that library's `from_dlpack`."""
+    import functools
+    import inspect
+
+    def deco(fn):
+        sig = inspect.signature(fn)
+
+        @functools.wraps(fn)
+        def wrapper(*args, **kwargs):
+            from . import _engine
+
+            bound = sig.bind(*args, **kwargs)
+            present = [n for n in names if n in bound.arguments and bound.arguments[n] is not None]
+            adopted, module = _engine._adopt_foreign([bound.arguments[n] for n in present])
+            for n, a in zip(present, adopted):
+                bound.arguments[n] = a
+            res = fn(*bound.args, **bound.kwargs)
+            if module is None:
+                return res
+            out = _engine._hand_back(res if isinstance(res, tuple) else (res,), module)
+            return out if isinstance(res, tuple) else out[0]
+
+        wrapper.__signature__ = sig
+        return wrapper
+
+    return deco
+
+
 def _dev_bytes(host_array, device):
     a = np.ascontiguousarray(host_array)
     alloc = _Allocation(max(a.nbytes, 16), device)
@@ -47,6 +79,7 @@ def _select_levels(A, B, levels):
     return A[half_idx], B[half_idx], out_half_idx
 
 
+@_foreign_aware("sp")
 def pressure_on_hybrid_levels(A, B, sp, levels=None, alpha_top="ifs", output="full", vertical_axis=0):
     """Pressure on hybrid full/half levels and the delta/alpha layer parameters (vertical.py:505-740)."""
     if isinstance(output, str):
@@ -221,6 +254,7 @@ def _chain(t, q, zs, A, B, sp, alpha_top, mode, vertical_axis):
     return res
 
 
+@_foreign_aware("t", "q", "alpha", "delta")
 def relative_geopotential_thickness_on_hybrid_levels_from_alpha_delta(t, q, alpha, delta, vertical_axis=0):
     """Geopotential thickness between the surface and the hybrid full levels from alpha and delta the caller
     already holds (outputs of `pressure_on_hybrid_levels`): vertical.py:741-893.  The same bottom-up column scan
@@ -266,16 +300,19 @@ def relative_geopotential_thickness_on_hybrid_levels_from_alpha_delta(t, q, alph
     return res
 
 
+@_foreign_aware("t", "q", "sp")
 def relative_geopotential_thickness_on_hybrid_levels(t, q, A, B, sp, alpha_top="ifs", vertical_axis=0):
     """Geopotential thickness between the surface and the hybrid full levels (vertical.py:894-994)."""
     return _chain(t, q, None, A, B, sp, alpha_top, _GEO_MODE["thickness"], vertical_axis)
 
 
+@_foreign_aware("t", "q", "zs", "sp")
 def geopotential_on_hybrid_levels(t, q, zs, A, B, sp, alpha_top="ifs", vertical_axis=0):
     """Geopotential on hybrid full levels (vertical.py:997-1069)."""
     return _chain(t, q, zs, A, B, sp, alpha_top, _GEO_MODE["geopotential"], vertical_axis)
 
 
+@_foreign_aware("t", "q", "zs", "sp")
 def height_on_hybrid_levels(t, q, zs, A, B, sp, alpha_top="ifs", h_type="geometric", h_reference="ground",
                             vertical_axis=0):
     """Geometric / geopotential height above sea level / ground on hybrid full levels (vertical.py:1072-1188)."""

@@ -63,7 +63,20 @@ with torch.cuda.stream(side):
     assert np.array_equal(strided.cpu().numpy(), ek.thermo.saturation_vapour_pressure(np.ascontiguousarray(t.T)), equal_nan=True)
     host_t = ek.thermo.potential_temperature(torch.from_numpy(t), torch.from_numpy(p))   # CPU tensors: NumPy semantics
     assert isinstance(host_t, np.ndarray)
-    del out, es_, td_, rh_, mixed, plain, strided
+    # the vertical functions take foreign arrays the same way (ekm_hip.vertical._foreign_aware)
+    A_, B_ = ek.vertical.hybrid_level_parameters(137)
+    sp_t = torch.full((64, 32), 101325.0, device=dev) * (1.0 - 0.3 * torch.rand(64, 32, device=dev))
+    pf = ek.vertical.pressure_on_hybrid_levels(A_.astype(np.float32), B_.astype(np.float32), sp_t)
+    assert isinstance(pf, torch.Tensor) and tuple(pf.shape) == (137, 64, 32) and pf.dtype == torch.float32
+    pf_host = ek.vertical.pressure_on_hybrid_levels(A_.astype(np.float32), B_.astype(np.float32), sp_t.cpu().numpy())
+    assert np.array_equal(pf.cpu().numpy(), pf_host)
+    t_t = torch.full((137, 64, 32), 250.0, device=dev) + 30.0 * torch.rand(137, 64, 32, device=dev)
+    q_t = torch.full((137, 64, 32), 1e-3, device=dev)
+    z = ek.vertical.relative_geopotential_thickness_on_hybrid_levels(t_t, q_t, A_.astype(np.float32), B_.astype(np.float32), sp_t)
+    z_host = ek.vertical.relative_geopotential_thickness_on_hybrid_levels(t_t.cpu().numpy(), q_t.cpu().numpy(), A_.astype(np.float32),
+                                                                          B_.astype(np.float32), sp_t.cpu().numpy())
+    assert isinstance(z, torch.Tensor) and np.array_equal(z.cpu().numpy(), z_host)
+    del out, es_, td_, rh_, mixed, plain, strided, pf, z
 torch.cuda.synchronize()
 
 # a second round on our own non-default stream: producer is handed that stream
