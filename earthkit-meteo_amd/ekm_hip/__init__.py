@@ -19,6 +19,7 @@ from .device import (  # noqa: F401
     empty_cache,
     memory_stats,
     order_streams,
+    pinned_empty,
     multi_gpu,
     set_device,
     set_stream,

@@ -303,6 +303,8 @@ _PAGE = 4096
 #   both            inputs pinned in place, results through the ring   43-54 GB/s
 # so no alternative is the default; they stay selectable and tested.
 _PINNED = os.environ.get("EKM_PIN_HOST", "0") == "1"
+_PINNED_OUT = os.environ.get("EKM_PINNED_RESULTS", "1") != "0"   # results of big NumPy calls in pooled pinned memory
+_PINNED_OUT_BYTES = int(os.environ.get("EKM_PINNED_RESULTS_BYTES", str(4 << 30)))
 
 
 class _Pinner:
@@ -405,7 +407,17 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
             raise _ffi.EkmError(f"{name}: one leading-axis row needs {row_bytes} B on the device, two do not fit the "
                                 f"streaming budget of {stream_budget_bytes(dev)} B on device {dev}")
         plans.append(pl)
-    outs = [np.empty(shape, out_dtype) for _ in range(nout)]
+    # Results of calls up to _PINNED_OUT_BYTES land in pinned host memory from a recycling pool (device.pinned_empty):
+    # the downloads are then plain DMAs -- no page faults, no pin / unpin around every copy.  Beyond that (or when
+    # pinned memory cannot be had) ordinary arrays, prefaulted slice by slice.
+    outs, pinned_outs = None, False
+    if _PINNED_OUT and nout * int(np.prod(shape, dtype=np.int64)) * out_dtype.itemsize <= _PINNED_OUT_BYTES:
+        from .device import pinned_empty
+
+        outs = [pinned_empty(shape, out_dtype) for _ in range(nout)]
+        pinned_outs = all(o is not None for o in outs)
+    if not pinned_outs:
+        outs = [np.empty(shape, out_dtype) for _ in range(nout)]
     errors = []
     slices, ready, max_rows = [], {}, []  # per device: its slices in order (and the longest); per slice: "its result pages exist" event
     for (lo, hi), (lanes, nslices) in zip(blocks, plans):
@@ -441,7 +453,7 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
                                 return
                             for ptr, nb in slice_ranges(lo, hi):
                                 pinner.pin(ptr, nb)
-                        if not pin_out and outs[0][lo:hi].nbytes >= _PRETOUCH_BYTES // 8:
+                        if not pin_out and not pinned_outs and outs[0][lo:hi].nbytes >= _PRETOUCH_BYTES // 8:
                             for o in outs:
                                 lib.ekm_host_prefault(o[lo:hi].ctypes.data, o[lo:hi].nbytes, 4)
                         ready[mine[k]].set()

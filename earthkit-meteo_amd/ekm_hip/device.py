@@ -231,8 +231,9 @@ _stagger_seq = itertools.count()
 
 
 def empty_cache():
-    """Return every cached device block to HIP (like torch.cuda.empty_cache)."""
+    """Return every cached device block to HIP (like torch.cuda.empty_cache), and the cached pinned host blocks."""
     _cache.drain()
+    _pinned.drain()
 
 
 def memory_stats(dev=None, reset_peak=False):
@@ -460,6 +461,84 @@ def _resolve_shape(shape, size):
     if int(np.prod(shape, dtype=np.int64)) != size:
         raise ValueError(f"cannot reshape array of size {size} into shape {tuple(shape)}")
     return tuple(shape)
+
+
+class _PinnedPool:
+    """Pinned (page-locked) host blocks for the results of big NumPy-in / NumPy-out calls, and for callers who want
+    their inputs in pinned memory (`ekm_hip.pinned_empty`).
+
+    A device-to-host copy into pinned memory is a plain DMA at the link rate (57 GB/s on the GPU box), with no page
+    faults and none of the pin / unpin work the runtime does around every copy into pageable memory.  hipHostMalloc is
+    slow (it pins page by page), so blocks are recycled: the NumPy array handed to the caller owns its block through a
+    finalizer, and when the caller drops the array (and every view of it) the block comes back here.  Cached blocks
+    are bounded by EKM_PINNED_CACHE_BYTES (default 8 GiB); beyond that they are freed."""
+
+    def __init__(self):
+        self.free = {}    # bucket -> [ptr, ...]
+        self.cached = 0
+        self.limit = int(os.environ.get("EKM_PINNED_CACHE_BYTES", str(8 << 30)))
+        self.lock = threading.Lock()
+        self.handed_out = 0
+
+    @staticmethod
+    def bucket(nbytes):
+        step = 1 << 20
+        return max(step, (int(nbytes) + step - 1) // step * step)
+
+    def take(self, nbytes):
+        b = self.bucket(nbytes)
+        with self.lock:
+            lst = self.free.get(b)
+            if lst:
+                self.cached -= b
+                self.handed_out += b
+                return lst.pop(), b
+        out = C.c_void_p()
+        if _ffi.lib().ekm_host_alloc(b, C.byref(out)) < 0 or not out.value:
+            return None, b
+        with self.lock:
+            self.handed_out += b
+        return out.value, b
+
+    def give(self, ptr, b):
+        with self.lock:
+            self.handed_out -= b
+            if self.cached + b <= self.limit:
+                self.free.setdefault(b, []).append(ptr)
+                self.cached += b
+                return
+        try:
+            _ffi.lib().ekm_host_free(ptr)
+        except Exception:  # interpreter shutdown
+            pass
+
+    def drain(self):
+        with self.lock:
+            items, self.free, self.cached = self.free, {}, 0
+        for lst in items.values():
+            for ptr in lst:
+                _ffi.lib().ekm_host_free(ptr)
+
+
+_pinned = _PinnedPool()
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """A NumPy array in pinned host memory (or None when pinned memory cannot be had): transfers to and from it are
+    plain DMAs.  The memory returns to a pool when the array and all its views are gone."""
+    import weakref
+
+    dtype = np.dtype(dtype)
+    shape = (shape,) if np.isscalar(shape) else tuple(int(s) for s in shape)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    ptr, b = _pinned.take(max(nbytes, 1))
+    if ptr is None:
+        return None
+    buf = (C.c_char * max(nbytes, 1)).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+    # `buf` is the base object every view of `arr` keeps alive: when it goes, the block returns to the pool
+    weakref.finalize(buf, _pinned.give, ptr, b)
+    return arr
 
 
 def to_device(array, device=None, dtype=None):

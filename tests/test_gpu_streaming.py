@@ -59,6 +59,45 @@ def test_alternative_transfer_routes_are_bit_equal(ek, monkeypatch, route):
     assert np.array_equal(got64, _device_path(ek, "potential_temperature", (t, p))[0])
 
 
+def test_big_numpy_results_live_in_pooled_pinned_memory(ek):
+    """Results of a streamed NumPy call come in pinned host memory from a recycling pool (device.pinned_empty): they are
+    ordinary writable NumPy arrays, results of successive calls never alias while both are alive, a block returns to
+    the pool only when the array AND its views are gone, and inputs in pinned memory work the same."""
+    import gc
+
+    from ekm_hip import device
+
+    t, q, p = _fields(16, 1 << 21)
+    want = _device_path(ek, "pipeline_svp_td_rh", (t, q, p))
+    first = ek.thermo.pipeline_svp_td_rh(t, q, p)
+    second = ek.thermo.pipeline_svp_td_rh(t, q * np.float32(0.5), p)   # while `first` is alive: other blocks
+    addr = lambda a: a.__array_interface__["data"][0]  # noqa: E731
+    assert len({addr(a) for a in first + second}) == 6 and all(a.flags.writeable and a.flags.c_contiguous for a in first)
+    for g, w in zip(first, want):
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+    view = first[0][3:5]                                   # a view keeps the whole block alive
+    kept = addr(first[0])
+    held = device._pinned.handed_out
+    del first
+    gc.collect()
+    assert device._pinned.handed_out == held - 2 * device._pinned.bucket(t.nbytes)   # two of the three came back
+    third = ek.thermo.pipeline_svp_td_rh(t, q, p)
+    assert kept not in {addr(a) for a in third}           # ... the viewed block was not handed out again
+    assert np.array_equal(view, want[0][3:5])
+    third[0][0, :8] = 0.0                                  # writable like any array
+    # inputs in pinned memory (ekm_hip.pinned_empty): same results
+    pin = [ek.pinned_empty(a.shape, a.dtype) for a in (t, q, p)]
+    for dst, src in zip(pin, (t, q, p)):
+        dst[...] = src
+    fourth = ek.thermo.pipeline_svp_td_rh(*pin)
+    for g, w in zip(fourth, want):
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+    del second, third, fourth, view, pin
+    gc.collect()
+    ek.empty_cache()
+    assert device._pinned.cached == 0 and device._pinned.handed_out == 0
+
+
 def test_streaming_stays_within_a_capped_device_budget(ek, monkeypatch):
     """fields whose working set exceeds the device budget stream through in slices, two or
     more in flight, device blocks recycled between slices.  Budget capped at 96 MiB against a 768 MiB

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "earthkit-meteo_amd")]
 from ekm_hip import _ffi  # noqa: E402
 
-INNER = 1800 * 3600
+INNER = int(os.environ.get("EKM_SWEEP_INNER", str(1800 * 3600)))  # points per level
 W = {  # workload: entry, operands, ints, nout, bytes/pt (field p)
     "full": ("pipeline_full", "tqp", (), 6, 36), "p3": ("pipeline_svp_td_rh", "tqp", (), 3, 24),
     "wetbulb": ("wet_bulb_temperature_from_specific_humidity", "tqp", (0, 1), 1, 16),
