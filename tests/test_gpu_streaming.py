@@ -78,7 +78,7 @@ def test_big_numpy_results_live_in_pooled_pinned_memory(ek):
     view = first[0][3:5]                                   # a view keeps the whole block alive
     kept = addr(first[0])
     held = device._pinned.handed_out
-    del first
+    del first, g, w
     gc.collect()
     assert device._pinned.handed_out == held - 2 * device._pinned.bucket(t.nbytes)   # two of the three came back
     third = ek.thermo.pipeline_svp_td_rh(t, q, p)
@@ -92,7 +92,7 @@ def test_big_numpy_results_live_in_pooled_pinned_memory(ek):
     fourth = ek.thermo.pipeline_svp_td_rh(*pin)
     for g, w in zip(fourth, want):
         assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
-    del second, third, fourth, view, pin
+    del second, third, fourth, view, pin, g, w, dst, src
     gc.collect()
     ek.empty_cache()
     assert device._pinned.cached == 0 and device._pinned.handed_out == 0
