@@ -486,7 +486,8 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
                 # slices differ by one row: every slice's device blocks are sized for the LONGEST slice, so a lane takes
                 # back exactly the blocks it released (same bucket) and the footprint stays lanes x slice, live + cached
                 handoff.put(((lo, hi), _submit(name, part, ints, eps, dtype, host_out=[o[lo:hi] for o in outs],
-                                               reserve_rows=(hi - lo, most), staged=_STAGED, copier=pinner)))
+                                               reserve_rows=(hi - lo, most), staged=_STAGED, copier=pinner,
+                                               staged_down=_STAGED and not pinned_outs)))
                 if trace is not None:
                     trace.append(("up", k, t0, t1, _time.perf_counter()))
         except BaseException as exc:  # surfaced in the calling thread
@@ -578,7 +579,7 @@ def _copy_staged(dev, to_device, pairs, stream):
 
 
 def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=None, reserve_rows=None, staged=False,
-            copier=None):
+            copier=None, staged_down=None):
     """Upload what lives on the host, launch, return without waiting for the kernel (the uploads themselves are
     synchronous copies on the current stream).  `reserve_rows` = (rows of this slice, rows of the longest slice):
     field-sized device blocks are reserved at the longest slice's size (streamed path)."""
@@ -659,7 +660,8 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
     _ffi.check(fn(*cargs))
     pend = _Pending()
     pend.plan, pend.results, pend.temps, pend.host_out = plan, results, temps, host_out
-    pend.internal_out, pend.toucher, pend.stream, pend.staged = internal_out, toucher, stream, staged
+    pend.internal_out, pend.toucher, pend.stream = internal_out, toucher, stream
+    pend.staged = staged if staged_down is None else staged_down  # results through the staging ring (not into pinned memory)
     pend.copier, pend.keep = copier, keep
     return pend
 
