@@ -471,12 +471,14 @@ class _PinnedPool:
     faults and none of the pin / unpin work the runtime does around every copy into pageable memory.  hipHostMalloc is
     slow (it pins page by page), so blocks are recycled: the NumPy array handed to the caller owns its block through a
     finalizer, and when the caller drops the array (and every view of it) the block comes back here.  Cached blocks
-    are bounded by EKM_PINNED_CACHE_BYTES (default 8 GiB); beyond that they are freed."""
+    are bounded by EKM_PINNED_CACHE_BYTES (default 8 GiB), beyond that they are freed; and once the callers hold
+    EKM_PINNED_LIVE_BYTES (default 32 GiB) of pinned results alive, further results are ordinary pageable arrays."""
 
     def __init__(self):
         self.free = {}    # bucket -> [ptr, ...]
         self.cached = 0
         self.limit = int(os.environ.get("EKM_PINNED_CACHE_BYTES", str(8 << 30)))
+        self.live_limit = int(os.environ.get("EKM_PINNED_LIVE_BYTES", str(32 << 30)))  # pinned bytes callers may hold at once
         self.lock = threading.Lock()
         self.handed_out = 0
 
@@ -493,6 +495,8 @@ class _PinnedPool:
                 self.cached -= b
                 self.handed_out += b
                 return lst.pop(), b
+            if self.handed_out + b > self.live_limit:
+                return None, b  # the caller keeps many results alive: further ones are ordinary pageable arrays
         out = C.c_void_p()
         if _ffi.lib().ekm_host_alloc(b, C.byref(out)) < 0 or not out.value:
             return None, b
