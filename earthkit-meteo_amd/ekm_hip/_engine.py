@@ -434,7 +434,7 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
     # qualify: C-contiguous, already in the compute dtype, spanning the leading axis.
     pinner = _Pinner() if _PINNED else None  # with _STAGED too: inputs pinned in place, results through the staging ring
     pin_in = [h for h, sp in zip(host, spans) if sp and h.flags.c_contiguous and h.dtype == cdtype] if pinner else []
-    pin_out = outs if pinner and out_dtype == cdtype and not _STAGED else []
+    pin_out = outs if pinner and out_dtype == cdtype and not _STAGED and not pinned_outs else []  # (pool blocks are pinned already)
     pin_ahead = [threading.Semaphore(depth + 2) for depth, _n in plans]
 
     def slice_ranges(lo, hi):

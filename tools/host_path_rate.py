@@ -19,10 +19,11 @@ from oracle import synthetic  # noqa: E402
 for nlev in (8, 32):
     t, q, p, _ = synthetic.make_fields(nlev, 1800 * 3600, dtype=np.float32, seed=3)
     n = t.size
-    for mode in ("pageable", "pooled", "pooled+in", "staged", "pinned", "mixed"):
+    for mode in ("pageable", "pooled", "pooled+pinin", "pooled+in", "staged", "pinned", "mixed"):
         # mixed: inputs pinned in place, results through the ring; pooled: results in pooled pinned memory (the default);
         # pooled+in: the caller's inputs in pinned memory too (ekm_hip.pinned_empty)
-        _engine._STAGED, _engine._PINNED = mode in ("staged", "mixed"), mode in ("pinned", "mixed")
+        # pooled+pinin: results pooled AND the caller's (pageable) inputs pinned in place slice by slice ahead of the uploads
+        _engine._STAGED, _engine._PINNED = mode in ("staged", "mixed"), mode in ("pinned", "mixed", "pooled+pinin")
         _engine._PINNED_OUT = mode.startswith("pooled")
         args3 = (t, q, p)
         if mode == "pooled+in":
