@@ -1,5 +1,5 @@
-"""Parity on EVERY point of the benchmark field, driver-run: the censuses that used to live in
-tools/full_parity.py as -m gpu tests.  3600 x 1800 x 137 = 887,760,000 grid points per field; the kernels run on the
+"""Parity on EVERY point of the benchmark field, driver-run: the censuses that round 2 ran from a
+builder tool (tools/full_parity.py, now removed), as -m gpu tests.  3600 x 1800 x 137 = 887,760,000 grid points per field; the kernels run on the
 whole field, the NumPy oracle checks it level by level on a pool of host processes (oracle/census.py::run_levels:
 the downloads land in shared memory the workers map, nothing is pickled).
 

@@ -12,7 +12,7 @@ The three big configurations run the kernel on all 887,760,000 points; the oracl
 core) checks EVERY point of a block of whole levels on a pool of host processes (cfg3/cfg5: 2 levels = 13 M
 points; cfg4: the 8 lowest-pressure levels = 52 M points, where the Davies-Jones regime guesses differ most
 and a wrong regime decision is visible) plus 256-point windows from 35 levels spread over the column.
-tools/full_parity.py does all 137 levels (profiles/r02_full_parity.json).
+tests/test_gpu_census.py does all 137 levels of every pressure mode.
 """
 import ctypes as C
 import multiprocessing as mp
