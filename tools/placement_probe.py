@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--pad-mb", type=int, default=0, help="extra MiB allocated between sets (shifts later sets)")
     ap.add_argument("--arena", action="store_true", help="carve the nine fields of a set out of ONE allocation")
+    ap.add_argument("--slack-mb", type=int, default=16, help="room after every field for the skews (k-th array: k*skew bytes)")
     ap.add_argument("--skews", default="0", help="comma list of byte skews: the k-th array of a set is used at base + k*skew")
     a = ap.parse_args()
     lib = _ffi.lib()
@@ -44,11 +45,11 @@ def main():
     sets = []
     for s in range(a.sets):
         if a.arena:
-            per = (4 * N + (16 << 20) + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+            per = (4 * N + (a.slack_mb << 20) + (2 << 20) - 1) // (2 << 20) * (2 << 20)
             base = dmalloc(9 * per)
             bufs = [base + k * per for k in range(9)]
         else:
-            bufs = [dmalloc(4 * N + (16 << 20)) for _ in range(9)]
+            bufs = [dmalloc(4 * N + (a.slack_mb << 20)) for _ in range(9)]
         small = []
         for arr in (A, B, sp, sp):
             ptr = dmalloc(arr.nbytes)
