@@ -35,6 +35,16 @@ NLEV, NLAT, NLON = 137, 1800, 3600
 INNER = NLAT * NLON
 N3 = NLEV * INNER
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0  # same guide: float4 copy, measured
+# VALU issue roof.  Peak by the guide: a wave64 VALU instruction issues over 2 clocks on a SIMD-32, 4 SIMDs x 256 CUs,
+# 2.4 GHz: 0.5 x 1024 x 2.4e9 x 64 lanes.  Achievable: what tools/microbench/valu_rates.hip sustains (v_fma_f32: 0.381
+# wave-instr/clk/SIMD, profiles/r03_valu_microbench.txt).  One issue unit = one plain fp32 VALU wave-instruction; the
+# weights of the other classes are their issue time relative to it: fp32 transcendentals issue at a quarter of the
+# plain rate (4), fp64 arithmetic at half (2; spec 78.6 vs 157.3 TFLOP/s), v_rcp_f64 3.3 x an fp64 fma (6.6; measured).
+VALU_PEAK_UNITS = 0.5 * 1024 * 2.4e9 * 64
+VALU_ACHIEVABLE_UNITS = 5.99e13
+VALU_WEIGHTS = {"SQ_INSTS_VALU_TRANS_F32": 4.0, "SQ_INSTS_VALU_ADD_F64": 2.0, "SQ_INSTS_VALU_MUL_F64": 2.0,
+                "SQ_INSTS_VALU_FMA_F64": 2.0, "SQ_INSTS_VALU_TRANS_F64": 6.6}
 
 # workload -> (entry point, inputs, outputs, algorithmic bytes/point fp32 with p a full field, oracle call)
 WORKLOADS = {
@@ -81,6 +91,13 @@ def parse():
                     help="roofline.traffic: 'measure' = two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of a short run of this "
                          "same command as child processes after the timed region (N = 1 only; falls back to 'file' if the "
                          "profiler is unavailable); 'file' = the committed profiles/traffic_latest.json; 'none' = null")
+    ap.add_argument("--valu", default="measure", choices=["measure", "file", "none"],
+                    help="roofline VALU side (executed issue units per point): 'measure' = a third rocprofv3 child pass of this "
+                         "command (--pmc SQ_INSTS_VALU ..., N = 1 only; falls back to 'file' with the reason stated); 'file' = the "
+                         "committed profiles/valu_latest.json; 'none' = HBM roof only")
+    ap.add_argument("--sustain", type=float, default=2.0,
+                    help="after the timed region, keep launching the same step back to back for at least this many seconds and "
+                         "report it as `sustained` (0 = skip); K timed steps stay what --steps asked for")
     ap.add_argument("--tiles", type=int, default=0)
     ap.add_argument("--unroll", type=int, default=0)
     return ap.parse_args()
@@ -218,6 +235,14 @@ class Dist:
         self.td.all_gather(out, mine)
         return [o.tolist() for o in out]
 
+    def gather_object(self, obj):
+        """Every rank's (picklable) object on every rank, rank order."""
+        if not self.td:
+            return [obj]
+        out = [None] * self.world
+        self.td.all_gather_object(out, obj)
+        return out
+
     def close(self):
         if self.td:
             self.td.destroy_process_group()
@@ -258,6 +283,56 @@ def plan_shard(workload, pmode, scaling, rank, world, nlev=NLEV, inner=INNER):
         lo, hi = shard_bounds(n_field, world)[rank]
         d.update(first=lo, n_local=hi - lo, lev0=lo // inner, lev1=-(-hi // inner), cut="grid points")
     return d
+
+
+def build_inputs(args, sh, dev, nlev, np_dtype, seed):
+    """The synthetic inputs of one shard (`sh` from plan_shard) on device `dev`, generated there: t, q, p (None unless p is a
+    full field), the level-pressure vector and, for hybrid levels, the shard's A/B tables + surface pressure.  The generator
+    is counter-based on the GLOBAL point index, so a grid-point or level shard holds exactly the values the whole field has
+    at its points (tests/test_gpu_streaming.py regenerates the whole field with world = 1 and compares; a column shard
+    of the column workloads is its own [level, column] field)."""
+    from ekm_hip import _ffi
+    from ekm_hip.device import DeviceArray
+
+    lib = _ffi.lib()
+    first, n_local = sh["first"], sh["n_local"]
+    shape = (n_local,)
+    lev0, lev1, col0, col1 = sh["lev0"], sh["lev1"], sh["col0"], sh["col1"]
+    nlev_loc, ncol = lev1 - lev0, col1 - col0   # this shard's levels / columns
+    t = DeviceArray.empty(shape, np_dtype, dev)
+    q = DeviceArray.empty(shape, np_dtype, dev)
+    p = DeviceArray.empty(shape, np_dtype, dev) if args.pmode == "field" else None
+    plev = DeviceArray.empty((nlev,), np_dtype, dev)
+    _ffi.check(getattr(lib, f"ekm_synth_levels_{args.dtype}")(dev, None, plev.ptr, nlev))
+    hyb = None
+    if args.pmode == "hybrid" or args.workload == "hybrid_levels":
+        # IFS L137 half-level tables (ekm_hip.vertical.hybrid_level_parameters, shipped inside the package); a level
+        # shard takes the half levels lev0 .. lev1 of the table, a column shard its columns of sp
+        assert nlev <= 137, "hybrid mode: at most the 137 IFS levels"
+        from ekm_hip.vertical import hybrid_level_parameters
+
+        A137, B137 = hybrid_level_parameters(137, model="ifs")
+        A = A137[137 - nlev:][lev0:lev1 + 1]
+        B = B137[137 - nlev:][lev0:lev1 + 1]
+        rng = np.random.default_rng(20260313 if args.scaling == "strong" else seed)
+        sp_host = (101325.0 * (1.0 - 0.35 * rng.random(INNER) ** 3)).astype(np_dtype)  # mostly near sea level, some orography
+        sp_host = np.ascontiguousarray(sp_host[col0:col1])
+        hyb = dict(A=DeviceArray.from_host(A.astype(np_dtype), dev), B=DeviceArray.from_host(B.astype(np_dtype), dev),
+                   sp=DeviceArray.from_host(sp_host, dev), Ah=A, Bh=B, sph=sp_host)
+    if args.pmode == "hybrid":
+        # t, q drawn around the hybrid-level pressure (materialised once, then dropped)
+        ptmp = DeviceArray.empty(shape, np_dtype, dev)
+        _ffi.check(getattr(lib, f"ekm_pressure_on_hybrid_levels_{args.dtype}")(
+            dev, None, hyb["A"].ptr, hyb["B"].ptr, hyb["sp"].ptr, ncol, nlev_loc, None, None, 1,
+            float(np.log(2)), ptmp.ptr, None, None, None))
+        _ffi.check(getattr(lib, f"ekm_synth_fill_given_p_{args.dtype}")(dev, None, t.ptr, q.ptr, ptmp.ptr, first,
+                                                                         n_local, seed))
+        _ffi.check(lib.ekm_sync(dev))
+        ptmp.free()
+    else:
+        fill = getattr(lib, f"ekm_synth_fill_{args.dtype}")
+        _ffi.check(fill(dev, None, t.ptr, q.ptr, p.ptr if p else None, first, n_local, INNER, nlev, seed))
+    return t, q, p, plev, hyb
 
 
 def main():
@@ -308,40 +383,8 @@ def main():
         shape = (n_local,)
         lev0, lev1, col0, col1 = sh["lev0"], sh["lev1"], sh["col0"], sh["col1"]
         nlev_loc, ncol = lev1 - lev0, col1 - col0   # this shard's levels / columns
-        t = DeviceArray.empty(shape, np_dtype, dev)
-        q = DeviceArray.empty(shape, np_dtype, dev)
-        p = DeviceArray.empty(shape, np_dtype, dev) if args.pmode == "field" else None
         seed = 20260313 + (dist.rank if args.scaling == "weak" else 0)
-        plev = DeviceArray.empty((nlev,), np_dtype, dev)
-        _ffi.check(getattr(lib, f"ekm_synth_levels_{args.dtype}")(dev, None, plev.ptr, nlev))
-        hyb = None
-        if args.pmode == "hybrid" or args.workload == "hybrid_levels":
-            # IFS L137 half-level tables (ekm_hip.vertical.hybrid_level_parameters, shipped inside the package); a level
-            # shard takes the half levels lev0 .. lev1 of the table, a column shard its columns of sp
-            assert nlev <= 137, "hybrid mode: at most the 137 IFS levels"
-            from ekm_hip.vertical import hybrid_level_parameters
-
-            A137, B137 = hybrid_level_parameters(137, model="ifs")
-            A = A137[137 - nlev:][lev0:lev1 + 1]
-            B = B137[137 - nlev:][lev0:lev1 + 1]
-            rng = np.random.default_rng(20260313 if args.scaling == "strong" else seed)
-            sp_host = (101325.0 * (1.0 - 0.35 * rng.random(INNER) ** 3)).astype(np_dtype)  # mostly near sea level, some orography
-            sp_host = np.ascontiguousarray(sp_host[col0:col1])
-            hyb = dict(A=DeviceArray.from_host(A.astype(np_dtype), dev), B=DeviceArray.from_host(B.astype(np_dtype), dev),
-                       sp=DeviceArray.from_host(sp_host, dev), Ah=A, Bh=B, sph=sp_host)
-        if args.pmode == "hybrid":
-            # t, q drawn around the hybrid-level pressure (materialised once, then dropped)
-            ptmp = DeviceArray.empty(shape, np_dtype, dev)
-            _ffi.check(getattr(lib, f"ekm_pressure_on_hybrid_levels_{args.dtype}")(
-                dev, None, hyb["A"].ptr, hyb["B"].ptr, hyb["sp"].ptr, ncol, nlev_loc, None, None, 1,
-                float(np.log(2)), ptmp.ptr, None, None, None))
-            _ffi.check(getattr(lib, f"ekm_synth_fill_given_p_{args.dtype}")(dev, None, t.ptr, q.ptr, ptmp.ptr, first,
-                                                                             n_local, seed))
-            _ffi.check(lib.ekm_sync(dev))
-            ptmp.free()
-        else:
-            fill = getattr(lib, f"ekm_synth_fill_{args.dtype}")
-            _ffi.check(fill(dev, None, t.ptr, q.ptr, p.ptr if p else None, first, n_local, INNER, nlev, seed))
+        t, q, p, plev, hyb = build_inputs(args, sh, dev, nlev, np_dtype, seed)
         outs = [DeviceArray.empty(shape, np_dtype, dev) for _ in range(nout)]
 
         fn = getattr(lib, f"ekm_{entry}_{args.dtype}")
@@ -402,18 +445,55 @@ def main():
     elapsed = dist.reduce(elapsed, "max")  # the job took as long as its slowest rank
 
     ndev_seen, dev_used, my_ms = -1, -1, float("nan")
+    sustained = None
     if not args.dry_run:
         ms = C.c_float()
         _ffi.check(lib.ekm_event_elapsed_ms(dev, evs[0], evs[-1], C.byref(ms)))
         my_ms = ms.value / args.steps
         kernel_ms = dist.reduce(my_ms, "max")  # average launch duration, slowest rank
+        if args.sustain > 0:
+            # the same launch, back to back, for >= --sustain seconds (outside the K timed steps): what the chip holds once
+            # clocks and temperature have settled, and long enough for an external activity sampler to see a busy GPU
+            n_launch = max(args.steps, int(args.sustain * 1e3 / max(my_ms, 1e-3)) + 1)
+            n_launch = int(dist.reduce(n_launch, "max"))
+            e0, e1 = C.c_void_p(), C.c_void_p()
+            _ffi.check(lib.ekm_event_create(dev, C.byref(e0)))
+            _ffi.check(lib.ekm_event_create(dev, C.byref(e1)))
+            dist.barrier()
+            ts = time.perf_counter()
+            _ffi.check(lib.ekm_event_record(dev, e0, None))
+            for _ in range(n_launch):
+                step()
+            _ffi.check(lib.ekm_event_record(dev, e1, None))
+            sync()
+            wall = dist.reduce(time.perf_counter() - ts, "max")
+            _ffi.check(lib.ekm_event_elapsed_ms(dev, e0, e1, C.byref(ms)))
+            sus_ms = dist.reduce(ms.value / n_launch, "max")
+            sustained = {"launches": n_launch, "seconds": round(wall, 3), "ms_per_step": round(wall / n_launch * 1e3, 4),
+                         "kernel_ms": round(sus_ms, 4)}
         per_launch = []
         for k in range(args.steps):
             _ffi.check(lib.ekm_event_elapsed_ms(dev, evs[k], evs[k + 1], C.byref(ms)))
             per_launch.append(ms.value)
         ndev_seen, dev_used = ndev, dev
-        if dist.rank == 0:
-            parity = check_parity(args, t, q, p, plev, outs, sh, nlev, np_dtype, hyb)
+    # parity: rank 0 judges a sample of its own shard AND, at N > 1, a sample of the LAST rank's shard (whose first point is
+    # not point 0 of the field), which travels through the gather together with the sample's place in the global field
+    smp = None if args.dry_run else sample_shard(args, t, q, p, plev, outs, sh, nlev, np_dtype, hyb)
+    last_smp = dist.gather_object(smp if dist.rank == dist.world - 1 else None)
+    parity_last, shard_window = None, None
+    if not args.dry_run and dist.rank == 0:
+        parity = judge_sample(args, smp)
+        if dist.world > 1:
+            ls = last_smp[-1]
+            parity_last = dict(judge_sample(args, ls), rank=dist.world - 1)
+            parity["ok"] = bool(parity["ok"] and parity_last["ok"])
+            if ls["kind"] == "windows":  # lets a reader regenerate the field and check the shard's offset (tests do)
+                shard_window = {"rank": dist.world - 1, "global_index": ls["global_index"][0], "level": ls["levels"][0],
+                                "t": [float(x) for x in ls["t"][:8]], "q": [float(x) for x in ls["q"][:8]],
+                                "out0": [float(x) for x in ls["outs"][0][:8]]}
+            else:
+                shard_window = {"rank": dist.world - 1, "global_col0": ls["global_col0"], "t": [float(x) for x in ls["t"][0, :8]],
+                                "out": [float(x) for x in ls["out"][0, :8]]}
     # what every rank did: [kernel ms per launch, points it owns, hipGetDeviceCount() it saw, device it used]
     per_rank = [dict(rank=r, kernel_ms=None if v[0] != v[0] else round(v[0], 4), points=int(v[1]),
                      hip_device_count=int(v[2]), device=int(v[3]))
@@ -442,17 +522,37 @@ def main():
                     "kernel": entry, "bytes_per_point": bpp, "points_per_launch": n_local,
                     "kernel_ms": round(kernel_ms, 4),
                     "kernel_ms_median": round(float(np.median(per_launch)), 4),
-                    "kernel_ms_min": round(float(np.min(per_launch)), 4)}
-            valu = valu_from_profiles(args)
-            if args.workload.startswith("wetbulb") and valu:
-                # These kernels are bound by VALU issue (transcendentals at a quarter rate), not by HBM: the fraction is
-                # quoted against THAT roof -- executed issue units per point (SQ counters of this same command,
-                # committed) x points / kernel time, against what the VALU microbenchmark sustains on this part.
+                    "kernel_ms_min": round(float(np.min(per_launch)), 4),
+                    "hbm_achievable_gbs": HBM_ACHIEVABLE_GBS}
+            valu, why_not = None, "not collected (--valu none)"
+            if args.valu == "measure" and dist.world == 1 and args.workload not in COLUMN_WORKLOADS:
+                valu, why_not = measure_valu(args, n_local)
+            if valu is None and args.valu != "none":
+                valu = valu_from_profiles(args, "" if args.valu == "file" else why_not)
+            if valu:
+                # The VALU side, quoted the same way as the HBM side: executed issue units per point (SQ counters) x points /
+                # kernel time against the PART's peak -- MI355X_MICROARCH.md: one plain fp32 VALU wave-instruction per 2 clocks
+                # per SIMD = 0.5 x 1024 SIMDs x 2.4 GHz x 64 lanes = 7.86e13 lane-ops/s -- with what the issue-rate
+                # microbenchmark sustains (5.99e13) beside it as "achievable", like 8.0 vs 6.3 TB/s.  The roof with the larger
+                # fraction is the one that binds.
                 units = valu["units_per_point"] * n_local / (kernel_ms * 1e-3)
-                roof.update(bound="valu", achieved=float(f"{units:.4g}"), peak=valu["peak"], unit="issue-units/s",
-                            frac=round(units / valu["peak"], 4), issue_units_per_point=valu["units_per_point"],
-                            valu_source=valu["source"], hbm_achieved_gbs=round(achieved, 1),
-                            hbm_frac=round(achieved / HBM_PEAK_GBS, 4))
+                vfrac = units / VALU_PEAK_UNITS
+                roof.update(valu_issue_units_per_point=valu["units_per_point"], valu_achieved_units_per_s=float(f"{units:.4g}"),
+                            valu_peak_units_per_s=VALU_PEAK_UNITS, valu_achievable_units_per_s=VALU_ACHIEVABLE_UNITS,
+                            valu_frac=round(vfrac, 4), valu_frac_of_achievable=round(units / VALU_ACHIEVABLE_UNITS, 4),
+                            valu_source=valu["source"], valu_counters=valu.get("counters"))
+                if vfrac > roof["frac"]:
+                    roof.update(bound="valu", achieved=float(f"{units:.4g}"), peak=VALU_PEAK_UNITS, unit="issue-units/s",
+                                frac=round(vfrac, 4), hbm_achieved_gbs=round(achieved, 1),
+                                hbm_frac=round(achieved / HBM_PEAK_GBS, 4))
+            else:
+                roof["valu_source"] = why_not
+            if sustained:
+                s_ach = bpp * n_local / (sustained["kernel_ms"] * 1e-3) / 1e9
+                sustained["frac"] = round(s_ach / HBM_PEAK_GBS, 4) if roof["bound"] == "hbm" else round(
+                    roof["valu_issue_units_per_point"] * n_local / (sustained["kernel_ms"] * 1e-3) / VALU_PEAK_UNITS, 4)
+                sustained["hbm_frac"] = round(s_ach / HBM_PEAK_GBS, 4)
+                sustained["value"] = None if value is None else n_total / (sustained["ms_per_step"] * 1e-3)
         line = {
             "metric": "grid-points/sec for fused thermo pipeline; achieved HBM GB/s vs peak",
             "value": value, "unit": "grid-points/s", "n_gpus": dist.world, "steps": args.steps,
@@ -464,33 +564,75 @@ def main():
                                    f" p as {dict(field='full field', level='137-level vector in LDS', hybrid='hybrid levels formed in-kernel from sp + A/B tables')[args.pmode]}",
                        "entry_point": f"ekm_{entry}_{args.dtype}", "points_per_gpu": n_total // dist.world, "p_mode": args.pmode,
                        "points_total": n_total, "shard_cut": sh["cut"], "per_rank": per_rank},
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+            "roofline": roof, "sustained": sustained, "cpu_baseline": cpu, "parity": parity,
+            "parity_last_rank": parity_last, "shard_window_last_rank": shard_window,
             "hip_device_count": ndev_min, "devices_used": devices, "oversubscribed": oversub,
         }
+        if kernel_ms:
+            # `value` is the metric: points x steps / wall time between the barriers (slowest rank).  Beside it the same
+            # quantity from the HIP events of the slowest rank alone -- at N > 1 a strong-scaling step is under a millisecond
+            # and the barriers' exit skew is of that order, so the two differ; the event figure is a cross-check, not the metric.
+            line["value_from_kernel_ms"] = None if value is None else n_total / (kernel_ms * 1e-3)
+            line["value_is"] = "points x steps / wall time of the slowest rank (barrier to device sync); value_from_kernel_ms = points / slowest rank's HIP-event time per launch"
         if args.dry_run:
             line["dry_run"] = True
         print(json.dumps(line), flush=True)
     dist.close()
 
 
-def check_parity(args, t, q, p, plev, outs, sh, nlev, np_dtype, hyb=None):
-    """GPU outputs of the timed arrays (this rank's shard) vs the oracle on 256-point windows of 32 levels."""
-    tol = 1e-4 if args.dtype == "f32" else 1e-6
+def sample_shard(args, t, q, p, plev, outs, sh, nlev, np_dtype, hyb=None):
+    """Host copies of what the parity check needs from THIS rank's shard of the timed arrays: 256-point windows of up to 32
+    levels spread over the whole column (the column workloads: 64 whole columns), inputs and every output, plus where
+    the windows sit in the GLOBAL field.  Small enough to travel to rank 0 through the gather."""
     first, n_local, lev0 = sh["first"], sh["n_local"], sh["lev0"]
     by_columns = sh["cut"] == "columns"
     ncol = sh["col1"] - sh["col0"]  # row length of this shard's [level, column] layout
+    smp = {"workload": args.workload, "dtype": args.dtype, "first": int(first), "lev0": int(lev0), "col0": int(sh["col0"]),
+           "cut": sh["cut"]}
     if args.workload == "geopotential":  # whole columns: 64 columns x all levels
+        c0, nc = min(4321, max(0, ncol - 64)), min(64, ncol)
+        col = lambda a: np.stack([a.flat_slice(k * ncol + c0, k * ncol + c0 + nc).to_host() for k in range(nlev)])  # noqa: E731
+        smp.update(kind="columns", t=col(t), q=col(q), zs=hyb["zsh"][c0:c0 + nc], sp=hyb["sph"][c0:c0 + nc], A=hyb["Ah"], B=hyb["Bh"],
+                   out=col(outs[0]), global_col0=int(sh["col0"] + c0))
+        return smp
+    off = min(4321, max(0, (ncol if by_columns else INNER) - 256))
+    wins = []
+    for lev in np.linspace(0, nlev - 1, 32).round().astype(int):  # the whole column, hybrid top levels (1 Pa ...) included
+        lo = int(lev) * ncol + off if by_columns else int(lev) * INNER - first + off
+        if 0 <= lo and lo + 256 <= n_local:
+            wins.append((int(lev), lo))
+    wins = sorted(set(wins))
+    if not wins:
+        wins = [((first + 0) // INNER, 0)]
+    nwin = min(256, n_local)
+    grab = lambda a: np.concatenate([a.flat_slice(lo, lo + nwin).to_host() for _, lo in wins])  # noqa: E731
+    smp.update(kind="windows", levels=[w[0] for w in wins], t=grab(t), q=grab(q), outs=[grab(o) for o in outs],
+               global_index=[int(lo + (sh["col0"] if by_columns else first)) for _, lo in wins])
+    if hyb is not None:
         from oracle import vertical_oracle as vo
 
-        c0, nc = 4321, 64
-        col = lambda a: np.stack([a.flat_slice(k * ncol + c0, k * ncol + c0 + nc).to_host() for k in range(nlev)])  # noqa: E731
-        want = vo.geopotential_on_hybrid_levels(col(t), col(q), hyb["zsh"][c0:c0 + nc], hyb["Ah"].astype(np_dtype),
-                                                hyb["Bh"].astype(np_dtype), hyb["sph"][c0:c0 + nc])
-        got = col(outs[0]).astype(np.float64)
+        pf = vo.pressure_on_hybrid_levels(hyb["Ah"].astype(np_dtype), hyb["Bh"].astype(np_dtype), hyb["sph"][off:off + nwin])
+        smp["p"] = np.concatenate([pf[lev - lev0] for lev, _ in wins]).astype(np_dtype)
+    elif p is not None:
+        smp["p"] = grab(p)
+    else:
+        pl = plev.to_host()
+        smp["p"] = np.concatenate([np.full(nwin, pl[lev], np_dtype) for lev, _ in wins])
+    return smp
+
+
+def judge_sample(args, smp):
+    """GPU outputs of a shard sample (sample_shard) vs the oracle on the same inputs."""
+    tol = 1e-4 if args.dtype == "f32" else 1e-6
+    np_dtype = np.float32 if args.dtype == "f32" else np.float64
+    if smp["kind"] == "columns":
+        from oracle import vertical_oracle as vo
+
+        got = smp["out"].astype(np.float64)
         # bar: the reference's own fp32 tolerance for this chain (atol 10 m2/s2, rtol 1e-6), against the oracle
         # evaluated in fp64 on the same inputs (the fp32 reference is itself 2 % off in alpha for thin layers)
         want = vo.geopotential_on_hybrid_levels(*(np.asarray(x, np.float64) for x in (
-            col(t), col(q), hyb["zsh"][c0:c0 + nc], hyb["Ah"], hyb["Bh"], hyb["sph"][c0:c0 + nc])))
+            smp["t"], smp["q"], smp["zs"], smp["A"], smp["B"], smp["sp"])))
         with np.errstate(all="ignore"):
             aerr = np.abs(got - want)
             r = aerr / np.abs(want)
@@ -500,27 +642,8 @@ def check_parity(args, t, q, p, plev, outs, sh, nlev, np_dtype, hyb=None):
         return {"points": int(got.size), "max_rel_err": float(np.nanmax(r)), "max_abs_err": float(np.nanmax(aerr)),
                 "nan_mismatch": nanmm, "tolerance": "atol 10 m2/s2 + rtol 1e-6 (reference's fp32 bar)" if args.dtype == "f32" else tol,
                 "excluded_regime_boundary_points": 0, "ok": ok}
-    wins = []
-    for lev in np.linspace(0, nlev - 1, 32).round().astype(int):  # the whole column, hybrid top levels (1 Pa ...) included
-        lo = int(lev) * ncol + 4321 if by_columns else int(lev) * INNER - first + 4321
-        if 0 <= lo and lo + 256 <= n_local:
-            wins.append((int(lev), lo))
-    if not wins:
-        wins = [((first + 0) // INNER, 0)]
-    ht = np.concatenate([t.flat_slice(lo, lo + 256).to_host() for _, lo in wins])
-    hq = np.concatenate([q.flat_slice(lo, lo + 256).to_host() for _, lo in wins])
-    if hyb is not None:
-        from oracle import vertical_oracle as vo
-
-        pf = vo.pressure_on_hybrid_levels(hyb["Ah"].astype(np_dtype), hyb["Bh"].astype(np_dtype), hyb["sph"][4321:4321 + 256])
-        hp = np.concatenate([pf[lev - lev0] for lev, _ in wins]).astype(np_dtype)
-    elif p is not None:
-        hp = np.concatenate([p.flat_slice(lo, lo + 256).to_host() for _, lo in wins])
-    else:
-        pl = plev.to_host()
-        hp = np.concatenate([np.full(256, pl[lev], np_dtype) for lev, _ in wins])
+    ht, hq, hp, gouts = smp["t"], smp["q"], smp["p"], smp["outs"]
     want = (hp,) if args.workload == "hybrid_levels" else oracle_call(args.workload, ht, hq, hp)
-    grab = lambda o: np.concatenate([o.flat_slice(lo, lo + 256).to_host() for _, lo in wins])  # noqa: E731
     if args.workload.startswith("wetbulb_bisect"):
         # the 12-step sign search is quantised to 120/4096 K.  No point is excluded: every differing point must be a NaN
         # one of the reference's two precisions also has, or lie within 2 quanta of the fp32 / fp64 reference or of a
@@ -528,7 +651,7 @@ def check_parity(args, t, q, p, plev, outs, sh, nlev, np_dtype, hyb=None):
         from oracle import census
 
         method = args.workload.rsplit("_", 1)[1] if args.workload.count("_") > 1 else "ifs"
-        b = census.bisect_job(dict(t=ht, q=hq, p=hp, got=grab(outs[0]), method=method))[0]
+        b = census.bisect_job(dict(t=ht, q=hq, p=hp, got=gouts[0], method=method))[0]
         return {"points": int(ht.size), "identical": b["identical"], "one_quantum": b["one_quantum"],
                 "two_quanta": b["two_quanta"], "more_than_two_quanta": b["more"], "nan_mismatch": b["nan_mismatch"],
                 "differing_points_unanchored": b["differ_unanchored"], "max_rel_err": b["max_quanta"] * 120.0 / 4096.0 / 250.0,
@@ -537,8 +660,8 @@ def check_parity(args, t, q, p, plev, outs, sh, nlev, np_dtype, hyb=None):
                 "excluded_points": 0, "ok": bool(b["more"] == 0 and b["differ_unanchored"] == 0)}
     # No point is excluded: the kernels settle Davies-Jones regime ties in double (csrc/thermo_math.hpp::davies_regime)
     worst, nan_mismatch, explained = 0.0, 0, 0
-    for k, (o, w) in enumerate(zip(outs, want)):
-        g = grab(o).astype(np.float64)
+    for k, (o, w) in enumerate(zip(gouts, want)):
+        g = o.astype(np.float64)
         w = np.asarray(w, dtype=np.float64)
         nanmm = np.isnan(g) != np.isnan(w)
         with np.errstate(all="ignore"):
@@ -560,31 +683,44 @@ def check_parity(args, t, q, p, plev, outs, sh, nlev, np_dtype, hyb=None):
         worst = max(worst, float(r.max()) if r.size else 0.0)
     return {"points": int(ht.size), "max_rel_err": worst, "nan_mismatch": nan_mismatch, "tolerance": tol,
             "excluded_points": 0, "tw_misses_explained_by_reference_amplification": explained,
-            "levels_sampled": [int(w[0]) for w in wins][:1] + [int(w[0]) for w in wins][-1:],
+            "levels_sampled": smp["levels"][:1] + smp["levels"][-1:],
             "ok": bool(nan_mismatch == 0 and worst <= tol)}
 
 
-def valu_from_profiles(args):
-    """Executed VALU issue units per point of this workload (SQ_INSTS_VALU + 3 x SQ_INSTS_VALU_TRANS_F32 from a
-    rocprofv3 --pmc pass of this same command, tools/profile_valu.sh) and the issue rate the VALU microbenchmark
-    (tools/microbench/valu_rates.hip) sustains on this part, both committed in profiles/valu_latest.json."""
+def valu_units(counts):
+    """Issue units per point from per-point executed wave-instruction counts (x 64 lanes / points): every VALU instruction
+    counts 1, the slower classes their extra issue time (VALU_WEIGHTS - 1)."""
+    units = counts["SQ_INSTS_VALU"]
+    for name, w in VALU_WEIGHTS.items():
+        units += (w - 1.0) * counts.get(name, 0.0)
+    return units
+
+
+def valu_from_profiles(args, why=""):
+    """Executed VALU instructions per point of this workload by class, from a rocprofv3 --pmc pass of this same command
+    (tools/profile_valu.sh) committed in profiles/valu_latest.json; used when the in-run pass is unavailable."""
     try:
         with open(os.path.join(ROOT, "profiles", "valu_latest.json")) as f:
             d = json.load(f)
-        units = d["units_per_point"].get(f"{args.workload}:{args.pmode}:{args.dtype}")
-        if units is None:
+        counts = d["counts_per_point"].get(f"{args.workload}:{args.pmode}:{args.dtype}")
+        if counts is None:
             return None
-        return {"units_per_point": units, "peak": d["peak_issue_units_per_s"], "source": d["source"]}
+        return {"units_per_point": round(valu_units(counts), 2), "counters": {k: round(v, 2) for k, v in counts.items()},
+                "source": "profiles/valu_latest.json (" + d["source"] + "), committed; not re-measured in this run" + (f" ({why})" if why else "")}
     except Exception:
         return None
 
 
-def measure_traffic(args, entry):
-    """HBM bytes per step of THIS workload, measured now: two child runs of this script (3 timed steps each) under
-    `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` -- separate passes, the program
-    itself right after `--`, as /opt/skills/guides/MI355X_MICROARCH.md prescribes -- summed over the map kernels of one
-    step.  gfx950 corrections (same guide): the counters are in KiB, and FETCH_SIZE reports half of a 16-B-per-lane
-    streaming read.  Returns (bytes per step, description) or (None, why not)."""
+def _child_cmd(args, steps, warm):
+    return [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline",
+            "--traffic", "none", "--valu", "none", "--sustain", "0", "--workload", args.workload, "--pmode", args.pmode,
+            "--dtype", args.dtype, "--levels", str(args.levels)]
+
+
+def rocprof_pass(args, counters, steps=3, warm=1):
+    """One child run of this script under `rocprofv3 --pmc <counters> --kernel-trace` (the program itself right after `--`,
+    counters in a pass of their own, as /opt/skills/guides/MI355X_MICROARCH.md prescribes).  Returns ({kernel: {counter:
+    [value per launch]}}, None) for the kernels of the timed step, or (None, why not)."""
     import collections
     import csv
     import glob
@@ -594,38 +730,62 @@ def measure_traffic(args, entry):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not found"
-    steps, warm = 3, 1
     tmp = tempfile.mkdtemp(prefix="ekm_pmc_", dir="/tmp")
-    per_kernel = {}
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
-                   os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline", "--traffic", "none",
-                   "--workload", args.workload, "--pmode", args.pmode, "--dtype", args.dtype, "--levels", str(args.levels)]
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
-            if r.returncode != 0:
-                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
-            agg = collections.defaultdict(list)
-            for path in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(path)):
-                    if row["Counter_Name"] == counter:
-                        agg[row["Kernel_Name"]].append(float(row["Counter_Value"]))
-            per_kernel[counter] = {k: v for k, v in agg.items() if any(t in k for t in ("map_", "geopotential_columns", "hybrid_levels"))}
+        cmd = [exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", tmp, "--"] + _child_cmd(args, steps, warm)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+        if r.returncode != 0:
+            return None, f"rocprofv3 --pmc {' '.join(counters)} failed (rc {r.returncode})"
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for path in glob.glob(os.path.join(tmp, "**", "*_counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(path)):
+                if row["Counter_Name"] in counters:
+                    agg[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
         # the kernels of the timed step: launched warm-up + steps times (fill / table kernels run once)
-        total = 0.0
-        for counter, scale in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
-            ks = {k: v for k, v in per_kernel[counter].items() if len(v) == steps + warm}
-            if not ks:
-                return None, f"no kernel with {steps + warm} launches in the {counter} pass"
-            total += scale * sum(sum(v) / len(v) for v in ks.values())
-        return total, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child passes of this command, "
-                       f"{steps} steps each), KiB x 1024, FETCH_SIZE x 2 (gfx950: half of a 16-B/lane streaming read is reported), "
-                       "summed over the kernels of one step")
+        ks = {k: dict(v) for k, v in agg.items() if any(t in k for t in ("map_", "geopotential_columns", "hybrid_levels"))
+              and all(len(x) == steps + warm for x in v.values())}
+        if not ks:
+            return None, f"no kernel with {steps + warm} launches in the {' '.join(counters)} pass"
+        return ks, None
     except Exception as exc:  # the profiler must never take the benchmark down
-        return None, f"traffic measurement failed: {type(exc).__name__}: {exc}"
+        return None, f"profiler pass failed: {type(exc).__name__}: {exc}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def measure_traffic(args, entry):
+    """HBM bytes per step of THIS workload, measured now: two child runs of this script (3 timed steps each) under
+    `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` -- separate passes -- summed over
+    the map kernels of one step.  gfx950 corrections (MI355X_MICROARCH.md): the counters are in KiB, and FETCH_SIZE reports
+    half of a 16-B-per-lane streaming read.  Returns (bytes per step, description) or (None, why not)."""
+    total = 0.0
+    for counter, scale in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
+        ks, why = rocprof_pass(args, [counter])
+        if ks is None:
+            return None, why
+        total += scale * sum(sum(v[counter]) / len(v[counter]) for v in ks.values())
+    return total, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child passes of this command, "
+                   "3 steps each), KiB x 1024, FETCH_SIZE x 2 (gfx950: half of a 16-B/lane streaming read is reported), "
+                   "summed over the kernels of one step")
+
+
+def measure_valu(args, n_local):
+    """Executed VALU wave-instructions per point of THIS workload by class, measured now: one more child run under
+    `rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 [fp64 classes] --kernel-trace`, summed over the kernels of one
+    step, x 64 lanes / points.  Returns ({units_per_point, counters, source}, None) or (None, why not)."""
+    names = ["SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32"]
+    if args.dtype == "f64":
+        names += ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"]
+    ks, why = rocprof_pass(args, names)
+    if ks is None and args.dtype == "f64":
+        return None, why + "; the fp64 instruction classes are needed to weigh an fp64 kernel"
+    if ks is None:
+        return None, why
+    counts = {c: sum(sum(v.get(c, [0.0])) / max(1, len(v.get(c, [0.0]))) for v in ks.values()) * 64.0 / n_local for c in names}
+    return {"units_per_point": round(valu_units(counts), 2), "counters": {k: round(v, 2) for k, v in counts.items()},
+            "source": "measured in this run: rocprofv3 --pmc " + " ".join(names) + " (one child pass of this command, 3 steps), wave-"
+                      "instructions x 64 lanes / points, summed over the kernels of one step; issue units = every VALU instruction 1 + "
+                      "the extra issue time of the slower classes (fp32 transcendental 4, fp64 add/mul/fma 2, fp64 rcp/rsq/sqrt 6.6)"}, None
 
 
 def traffic_from_profiles(args, n_local):

@@ -3,6 +3,7 @@
 // Compiles ops.hpp / thermo_math.hpp with g++ so the exact formulas the gfx950
 // kernels run can be checked against the golden vectors in a container without
 // a GPU.  The product (ekm_hip) never loads this library and has no CPU path.
+#include <cmath>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -23,9 +24,34 @@ static int host_map(const T* const* ins, T* const* outs, size_t n, double rp) {
       ekm::OpTable<Op>::template fill<T>(tab.data(), 0, 1);
     }
   }
+  // fp64: the kernels' two passes (map_kernel.hpp::apply_points) -- fdouble first, whose primitives poison to NaN where
+  // the plain ones apply an IEEE special-operand fix-up, then plain double for a point with a non-finite output.
+  // EKM_TWIN_PLAIN_F64=1 skips the first pass.
+  const char* plain = std::getenv("EKM_TWIN_PLAIN_F64");  // read per call: tests compare the two in one process
+  const bool two_pass = !(plain && plain[0] == '1');
   for (size_t i = 0; i < n; ++i) {
     T x[Op::NIN], y[Op::NOUT];
     for (int k = 0; k < Op::NIN; ++k) x[k] = ins[k][i];
+    if constexpr (sizeof(T) == 8) {
+      if (two_pass) {
+        ekm::fdouble xf[Op::NIN], yf[Op::NOUT];
+        for (int k = 0; k < Op::NIN; ++k) xf[k] = ekm::fdouble(x[k]);
+        if constexpr (ekm::OpTable<Op>::elems > 0) {
+          if (!tab.empty())
+            ekm::OpTable<Op>::template apply<ekm::fdouble>(xf, yf, ekm::fdouble(rp), reinterpret_cast<const ekm::fdouble*>(tab.data()));
+          else
+            Op::template apply<ekm::fdouble>(xf, yf, ekm::fdouble(rp));
+        } else {
+          Op::template apply<ekm::fdouble>(xf, yf, ekm::fdouble(rp));
+        }
+        bool finite = true;
+        for (int k = 0; k < Op::NOUT; ++k) finite = finite && std::isfinite(yf[k].v);
+        if (finite) {
+          for (int k = 0; k < Op::NOUT; ++k) outs[k][i] = yf[k].v;
+          continue;
+        }
+      }
+    }
     if constexpr (ekm::OpTable<Op>::elems > 0) {
       if (!tab.empty())
         ekm::OpTable<Op>::template apply<T>(x, y, T(rp), tab.data());

@@ -37,6 +37,14 @@ constexpr int kThreads = EKM_THREADS;
 #ifndef EKM_WAVES_PER_EU
 #define EKM_WAVES_PER_EU 1
 #endif
+// fp64 kernels: fdouble first pass + plain-double redo of poisoned lanes (apply_points); 0 = plain double only
+#ifndef EKM_F64_TWO_PASS
+#if defined(EKM_F64_EXACT) || defined(EKM_F64_LIBM)
+#define EKM_F64_TWO_PASS 0
+#else
+#define EKM_F64_TWO_PASS 1
+#endif
+#endif
 
 template <class T>
 struct VecOf;
@@ -65,6 +73,7 @@ struct MapArgs {
   unsigned long long step_q[NIN];  // (elements per tile) / inner   resp. unused
   unsigned long long step_r[NIN];  // (elements per tile) % inner   resp. % len
   int vec_ok;                    // all field pointers 16-B aligned
+  int f64_plain;                 // fp64: redo every lane in plain double (tuning parameter f64_plain; tests / A-B only)
   const T* aux0;                 // EKM_HYBRID_FULL (last operand): A half-level table
   const T* aux1;                 //                                 B half-level table
 };
@@ -98,11 +107,26 @@ __device__ __forceinline__ void st_stream(T* p, typename VecOf<T>::type v) {
 
 // Ops with a per-workgroup LDS table (OpTable<Op>::elems > 0, ops.hpp): reserve it, fill it once, pass it on.
 template <class Op, class T>
-__device__ __forceinline__ void op_apply(const T* __restrict__ x, T* __restrict__ y, T rp, const T* __restrict__ tab) {
+__device__ __forceinline__ void op_apply_as(const T* __restrict__ x, T* __restrict__ y, T rp, const T* __restrict__ tab) {
   if constexpr (OpTable<Op>::elems > 0)
     OpTable<Op>::template apply<T>(x, y, rp, tab);
   else
     Op::template apply<T>(x, y, rp);
+}
+// One point.  fp64 goes through xdouble (thermo_math.hpp: plain primitives behind the same operator functions as the
+// first pass of apply_points), so that every fp64 path of a kernel rounds alike.
+template <class Op, class T>
+__device__ __forceinline__ void op_apply(const T* __restrict__ x, T* __restrict__ y, T rp, const T* __restrict__ tab) {
+  if constexpr (sizeof(T) == 8 && EKM_F64_TWO_PASS) {
+    xdouble xs[Op::NIN], ys[Op::NOUT];
+#pragma unroll
+    for (int i = 0; i < Op::NIN; ++i) xs[i] = xdouble(x[i]);
+    op_apply_as<Op, xdouble>(xs, ys, xdouble(rp), reinterpret_cast<const xdouble*>(tab));
+#pragma unroll
+    for (int o = 0; o < Op::NOUT; ++o) y[o] = ys[o].v;
+  } else {
+    op_apply_as<Op, T>(x, y, rp, tab);
+  }
 }
 // The V points of one lane's 16-B chunk.  Ops with a Davies-Jones regime decision inside (OpUsesTie) run them
 // branch-free first, only recording whether a point met a tie, and then -- in the ~0.3 % of waves where some lane
@@ -110,7 +134,8 @@ __device__ __forceinline__ void op_apply(const T* __restrict__ x, T* __restrict_
 // lets the compiler interleave the V independent points (4-8 % on the wet-bulb kernels).
 template <class Op, class T, int V>
 __device__ __forceinline__ void apply_points(const T (&x)[V][Op::NIN], T (&y)[V][Op::NOUT], T rp,
-                                             const T* __restrict__ tab) {
+                                             const T* __restrict__ tab, int f64_plain) {
+  (void)f64_plain;
   if constexpr (OpUsesTie<Op>::value && sizeof(T) == 4 && OpTable<Op>::elems == 0) {
     TieFlag flag;
 #pragma unroll
@@ -122,6 +147,49 @@ __device__ __forceinline__ void apply_points(const T (&x)[V][Op::NIN], T (&y)[V]
         for (int j = 0; j < V; ++j) Op::template apply_tie<T>(x[j], y[j], rp, exact);
       }
     }
+  } else if constexpr (sizeof(T) == 8 && EKM_F64_TWO_PASS) {
+    // fp64: first pass in fdouble (thermo_math.hpp: primitives without special-operand fix-ups, which poison to NaN
+    // where a fix-up would have acted), then -- wave-uniform test, practically never taken on atmospheric data -- the
+    // lanes holding a non-finite output are redone in plain double, whose primitives treat IEEE specials as libm does.
+    fdouble xf[V][Op::NIN], yf[V][Op::NOUT];
+    unsigned fin = 0x7ff00000u;  // min over the outputs of (high dword & exponent mask): 0x7ff00000 - that == 0 iff inf / NaN
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+#pragma unroll
+      for (int i = 0; i < Op::NIN; ++i) xf[j][i] = fdouble(x[j][i]);
+      op_apply_as<Op, fdouble>(xf[j], yf[j], fdouble(rp), reinterpret_cast<const fdouble*>(tab));
+#pragma unroll
+      for (int o = 0; o < Op::NOUT; ++o) {
+        y[j][o] = yf[j][o].v;
+        const unsigned gap = 0x7ff00000u - ((unsigned)__double2hiint(yf[j][o].v) & 0x7ff00000u);
+        fin = gap < fin ? gap : fin;
+      }
+    }
+#ifndef EKM_CENSUS_FAST_ONLY  // (ISA census aid: the first pass alone)
+    const bool redo = fin == 0u || f64_plain != 0;  // f64_plain (tuning parameter, wave-uniform): every lane takes the plain pass
+    if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
+      if (redo) {
+        // one copy of the plain-double body, the point picked by selects: indexing x[j] / y[j] with a loop counter
+        // would put both arrays into scratch memory
+#pragma unroll 1
+        for (int j = 0; j < V; ++j) {
+          T xj[Op::NIN], yj[Op::NOUT];
+#pragma unroll
+          for (int i = 0; i < Op::NIN; ++i) {
+            xj[i] = x[0][i];
+#pragma unroll
+            for (int jj = 1; jj < V; ++jj) xj[i] = j == jj ? x[jj][i] : xj[i];
+          }
+          op_apply<Op, T>(xj, yj, rp, tab);
+#pragma unroll
+          for (int o = 0; o < Op::NOUT; ++o) {
+#pragma unroll
+            for (int jj = 0; jj < V; ++jj) y[jj][o] = j == jj ? yj[o] : y[jj][o];
+          }
+        }
+      }
+    }
+#endif
   } else {
 #pragma unroll
     for (int j = 0; j < V; ++j) op_apply<Op, T>(x[j], y[j], rp, tab);
@@ -193,7 +261,7 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_fields(const M
 #pragma unroll
           for (int i = 0; i < NIN; ++i) x[j][i] = xin[u][i][j];
         }
-        apply_points<Op, T, V>(x, y, a.rp, op_tab);
+        apply_points<Op, T, V>(x, y, a.rp, op_tab, a.f64_plain);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
 #pragma unroll
@@ -206,7 +274,11 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_fields(const M
   }
   // ragged tail: n % V single elements, done by the first lanes of workgroup 0
   const unsigned long long e = nvec * V + (unsigned long long)blockIdx.x * kThreads + threadIdx.x;
+#ifdef EKM_CENSUS_FAST_ONLY
+  if (false) {
+#else
   if (e < a.n) {
+#endif
     T x[NIN], y[NOUT];
 #pragma unroll
     for (int i = 0; i < NIN; ++i) x[i] = a.in[i][e];
@@ -310,7 +382,7 @@ __global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, 
 #pragma unroll
         for (int i = 0; i < NIN; ++i) x[j][i] = xin[i][j];
       }
-      apply_points<Op, T, V>(x, y, a.rp, op_tab);
+      apply_points<Op, T, V>(x, y, a.rp, op_tab, a.f64_plain);
 #pragma unroll
       for (int j = 0; j < V; ++j) {
 #pragma unroll
@@ -377,6 +449,7 @@ struct LevArgs {
   unsigned last;         // highest valid index of the level vector / full-level index
   unsigned lev_per_wg;   // consecutive levels one workgroup walks (WALK instantiation only; else 1)
   unsigned tiles;        // consecutive horizontal tiles per workgroup
+  int f64_plain;         // fp64: redo every lane in plain double (tuning parameter f64_plain; tests / A-B only)
   T rp;
 };
 
@@ -464,7 +537,7 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? OpWaves<Op>::value : EK
             for (int f = 0; f < PI; ++f) x[j][f] = xin[f][j];
             x[j][PI] = pressure(j);
           }
-          apply_points<Op, T, V>(x, y, a.rp, op_tab);
+          apply_points<Op, T, V>(x, y, a.rp, op_tab, a.f64_plain);
 #pragma unroll
           for (int j = 0; j < V; ++j) {
 #pragma unroll
@@ -520,6 +593,7 @@ int tuning_unroll();
 int tuning_lev_per_wg();    // EKM_HYBRID_FULL: consecutive levels one workgroup walks (EKM_LEV_PER_WG, default 0 = by stream count)
 int tuning_hybrid_band_bytes();  // EKM_HYBRID_FULL: bytes of surface pressure per band (EKM_HYBRID_BAND_KB, default 8192 KiB)
 int tuning_table_tiles();   // most tiles per workgroup for ops that keep an LDS table (EKM_TABLE_TILES, default 8)
+int tuning_f64_plain();      // fp64 map kernels: 1 = every lane redone in plain double (EKM_F64_PLAIN, default 0)
 int tuning_geo_chunk_levels();  // levels per launch of the geopotential column scan (EKM_GEO_CHUNK_LEVELS, default: all in one launch)
 
 constexpr unsigned kMaxLdsBytes = 64 * 1024;
@@ -566,6 +640,7 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
   a.aux0 = a.aux1 = nullptr;
   a.n = n;
   a.rp = T(rp);
+  a.f64_plain = tuning_f64_plain();
   bool bc = false, aligned = true;
   unsigned lds_elems = 0;
   for (int i = 0; i < NIN; ++i) {
@@ -676,6 +751,7 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
       la.B = a.aux1;
       la.n = n;
       la.rp = a.rp;
+      la.f64_plain = a.f64_plain;
       unsigned long long inner = a.inner[NIN - 1];
       la.last = pm == EKM_SCALAR ? 0u : a.len[NIN - 1] - 1u;
       if (pm == EKM_SCALAR) inner = n < (1ull << 30) ? n : (1ull << 30);  // one "level" of any convenient length

@@ -107,7 +107,7 @@ EKM_OP(OpTdFromRh, 2, 1, y[0] = t_from_es(es_water(x[0]) * x[1] * T(1.0 / 100.0)
 EKM_OP(OpTdFromQ, 2, 1, y[0] = t_from_es(e_from_q(x[0], x[1]));)
 // thermo.py:738-920
 EKM_OP(OpVirtualT, 2, 1, y[0] = virtual_t(x[0], x[1]);)
-EKM_OP(OpVirtualTheta, 3, 1, y[0] = theta(x[0], x[2]) * (T(1) + T(k::tv_c1) * x[1]);)
+EKM_OP(OpVirtualTheta, 3, 1, y[0] = theta(x[0], x[2]) * m_fma(T(k::tv_c1), x[1], T(1));)
 EKM_OP(OpTheta, 2, 1, y[0] = theta(x[0], x[1]);)
 EKM_OP(OpTFromTheta, 2, 1, y[0] = t_from_theta(x[0], x[1]);)
 EKM_OP(OpPOnDryAdiabat, 3, 1, y[0] = p_on_dry_adiabat(x[0], x[1], x[2]);)
@@ -147,7 +147,7 @@ struct OpWetBulbFromQ<EPT_IFS, T_NEWTON> {
     const T lte = m_log2(t * T(1.0 / 273.16)) + xe;        // log2(te/273.16) without forming te
     const TeFromTQP<T> exact{t, q, p};
     y[0] = t_on_ma_newton_ifs_core(
-        lte, p, T(0.1859e-5) * p + T(0.6512), [&] { return t * m_exp2(xe); },
+        lte, p, m_fma(T(0.1859e-5), p, T(0.6512)), [&] { return t * m_exp2(xe); },
         [&] { return m_exp2(T(k::kappa) * m_log2(p * T(1.0 / k::p0))); }, exact, tie);
   }
 };
@@ -298,7 +298,7 @@ struct OpUsesTie<OpWbptFromQ<M, T_NEWTON>> {
   static constexpr bool value = true;
 };
 // thermo.py:1678-1707
-EKM_OP(OpGasConstant, 1, 1, y[0] = T(k::Rd) + T(k::Rv - k::Rd) * x[0];)
+EKM_OP(OpGasConstant, 1, 1, y[0] = m_fma(T(k::Rv - k::Rd), x[0], T(k::Rd));)
 
 // wind/array/wind.py:192-222: hydrostatic vertical velocity w = (-Rd/g) * (omega*t/p)
 EKM_OP(OpWFromOmega, 3, 1, y[0] = T(-k::Rd / k::g) * m_div(x[0] * x[1], x[2]);)

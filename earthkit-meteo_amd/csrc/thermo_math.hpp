@@ -64,6 +64,71 @@ EKM_HD T nan_v() {
   return std::numeric_limits<T>::quiet_NaN();
 }
 
+// ---- fdouble: the fp64 kernels' FAST arithmetic type ----------------------------------------------------------
+// A double whose three primitives (m_rcp / m_exp2 / m_log2 below) carry NO special-operand fix-ups: for an operand
+// where the fixed-up primitive returns one of the IEEE specials (rcp(0) = inf, rcp(inf) = 0, exp2(+-inf), log2(0),
+// log2(inf)) they return NaN instead ("poison"), for every other operand exactly what the plain-double primitive
+// returns.  Everything downstream of a poisoned value is NaN (no formula of this file takes fmin/fmax of a
+// primitive's result or selects on a comparison alone without carrying the compared value), so a point whose fast
+// outputs are all finite got exactly the plain-double result, and the map kernels redo the lanes with a non-finite
+// output in plain double (map_kernel.hpp::apply_points).  What that buys: the static instruction stream of the
+// six-output fp64 pipeline held 121 v_cndmask + 65 v_cmp + 30 v_min/v_max per point for the fix-ups, a quarter of
+// its issue time, for operands atmospheric data never has.  The host twin runs the same two passes with libm-based
+// stand-ins of the poisoning primitives, so the golden edge cases check the re-run logic without a GPU.
+// xdouble is the same wrapper around the PLAIN primitives: the kernels' second pass and their element-wise paths run it
+// instead of a bare double, so that both passes are the same template instantiated over the same operator functions and
+// the compiler contracts a*b+c into fma at the same places -- the redo must reproduce the first pass bit for bit
+// wherever that was valid (tests/test_gpu_two_pass.py).
+EKM_HD double nc_add(double a, double b) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  return a + b;
+}
+EKM_HD double nc_mul(double a, double b) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+  return a * b;
+}
+template <bool FAST>
+struct fd64 {
+  double v;
+  fd64() = default;
+  EKM_HD constexpr fd64(double x) : v(x) {}
+  EKM_HD explicit operator double() const { return v; }
+  EKM_HD explicit operator float() const { return (float)v; }
+  EKM_HD explicit operator int() const { return (int)v; }
+  // hidden friends: found by argument-dependent lookup, so a bare constant on one side converts.
+  // The arithmetic operators do NOT contract (a product and a sum written with them stay two roundings): which pairs
+  // the compiler fuses otherwise differs between two instantiations of the same formula, and the two passes must round
+  // alike.  Where a formula wants a fused multiply-add it says so: m_fma / m_fms / m_fnma below.
+  EKM_HD friend fd64 operator+(fd64 a, fd64 b) { return fd64(nc_add(a.v, b.v)); }
+  EKM_HD friend fd64 operator-(fd64 a, fd64 b) { return fd64(nc_add(a.v, -b.v)); }
+  EKM_HD friend fd64 operator*(fd64 a, fd64 b) { return fd64(nc_mul(a.v, b.v)); }
+  EKM_HD friend fd64 operator-(fd64 a) { return fd64(-a.v); }
+  EKM_HD friend fd64& operator+=(fd64& a, fd64 b) { a.v = nc_add(a.v, b.v); return a; }
+  EKM_HD friend fd64& operator-=(fd64& a, fd64 b) { a.v = nc_add(a.v, -b.v); return a; }
+  EKM_HD friend fd64& operator*=(fd64& a, fd64 b) { a.v = nc_mul(a.v, b.v); return a; }
+  EKM_HD friend bool operator<(fd64 a, fd64 b) { return a.v < b.v; }
+  EKM_HD friend bool operator<=(fd64 a, fd64 b) { return a.v <= b.v; }
+  EKM_HD friend bool operator>(fd64 a, fd64 b) { return a.v > b.v; }
+  EKM_HD friend bool operator>=(fd64 a, fd64 b) { return a.v >= b.v; }
+  EKM_HD friend bool operator==(fd64 a, fd64 b) { return a.v == b.v; }
+  EKM_HD friend bool operator!=(fd64 a, fd64 b) { return a.v != b.v; }
+};
+typedef fd64<true> fdouble;
+typedef fd64<false> xdouble;
+#define EKM_FD template <bool F> EKM_HD
+template <>
+EKM_HD fdouble nan_v<fdouble>() {
+  return fdouble(std::numeric_limits<double>::quiet_NaN());
+}
+template <>
+EKM_HD xdouble nan_v<xdouble>() {
+  return xdouble(std::numeric_limits<double>::quiet_NaN());
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 EKM_HD float m_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 EKM_HD float m_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
@@ -150,8 +215,64 @@ EKM_HD double m_log2(double x) {
   return r;
 }
 #else
-// (Wave-uniform skipping of the special-operand fix-ups was tried and is slower: 19.9 vs 17.8 ms for the full
-// pipeline -- the branches stop the compiler from interleaving the four points of a lane.)
+// Shared pieces of the default (~1e-10) set.  The polynomial coefficients live in constant memory, NOT in the
+// instruction stream: v_fma_f64 cannot take a 64-bit literal, so with literal coefficients the compiler materialises
+// each one with two v_mov_b32 in front of a v_fmac_f64 (122 v_mov per point in the six-output pipeline, ~10 % of its
+// issue time; profiles/r03).  Read through the scalar cache they are SGPR pairs, loaded once per wave, that
+// v_fma_f64 takes directly as its addend.  (static: one copy per translation unit / device module.)
+static __constant__ double kF64Coef[16] = {
+    // 2^f on |f| <= 0.5, degree 7, near-minimax in relative error (4.0e-11), ln 2 folded in; ascending
+    0.9999999999616818, 0.693147180728452, 0.24022651198156714, 0.05550410353429554, 0.009618027253757476,
+    0.0013333922578355431, 0.00015469291117256424, 1.5201918192496034e-05,
+    // atanh(s)/s on z = s^2 in [0, 0.0295], degree 4 (4.2e-12); ascending
+    1.0000000000041798, 0.3333333262373743, 0.20000192337193154, 0.14267525468490147, 0.1180818033212343,
+    0.0, 0.0, 0.0};
+#if defined(EKM_F64_COEF_LITERAL)
+#define EKM_F64C(i, lit) (lit)
+#else
+#define EKM_F64C(i, lit) (kF64Coef[i])
+#endif
+EKM_HD double exp2_poly(double f) {  // 2^f, |f| <= 0.5
+  double p = EKM_F64C(7, 1.5201918192496034e-05);
+  p = __builtin_fma(p, f, EKM_F64C(6, 0.00015469291117256424));
+  p = __builtin_fma(p, f, EKM_F64C(5, 0.0013333922578355431));
+  p = __builtin_fma(p, f, EKM_F64C(4, 0.009618027253757476));
+  p = __builtin_fma(p, f, EKM_F64C(3, 0.05550410353429554));
+  p = __builtin_fma(p, f, EKM_F64C(2, 0.24022651198156714));
+  p = __builtin_fma(p, f, EKM_F64C(1, 0.693147180728452));
+  p = __builtin_fma(p, f, EKM_F64C(0, 0.9999999999616818));
+  return p;
+}
+EKM_HD double atanh_poly(double z) {  // atanh(s)/s, z = s^2
+  double p = EKM_F64C(12, 0.1180818033212343);
+  p = __builtin_fma(p, z, EKM_F64C(11, 0.14267525468490147));
+  p = __builtin_fma(p, z, EKM_F64C(10, 0.20000192337193154));
+  p = __builtin_fma(p, z, EKM_F64C(9, 0.3333333262373743));
+  p = __builtin_fma(p, z, EKM_F64C(8, 1.0000000000041798));
+  return p;
+}
+// v_cvt_i32_f64 saturates (+-2^31, NaN -> 0); the C cast is undefined out of range
+EKM_HD int cvt_sat_i32(double n) {
+  int i;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(i) : "v"(n));
+  return i;
+}
+// 1/a for a in [1, 4] (the log2 argument): v_rcp_f32 seed + one Newton step (<= 3e-14), ~21 clocks instead of ~28
+EKM_HD double rcp_small(double a) {
+  const double r0 = (double)__builtin_amdgcn_rcpf((float)a);
+  return __builtin_fma(r0, __builtin_fma(-a, r0, 1.0), r0);
+}
+// log2 of a positive finite x: x = m * 2^e with m in [0.7071, 1.4142) (the exponent of x*sqrt(2) puts the split at
+// sqrt(1/2)), 2*atanh(s), s = (m - 1)/(m + 1), |s| <= 0.1716
+EKM_HD double log2_core(double x) {
+  const int e = __builtin_amdgcn_frexp_exp(x * 1.41421356237309504880) - 1;
+  const double m = __builtin_amdgcn_ldexp(x, -e);
+  const double s = (m - 1.0) * rcp_small(m + 1.0);
+  return __builtin_fma(atanh_poly(s * s) * s, 2.0 * 1.44269504088896340736, (double)e);
+}
+
+// plain double: IEEE special operands handled as libm does.  Off the hot path since round 4 (the map kernels run
+// fdouble and come here only for the lanes it poisoned, for ragged ends and for unaligned input).
 EKM_HD double m_rcp(double x) {
   const double r0 = __builtin_amdgcn_rcp(x);
   const double e = __builtin_fma(-x, r0, 1.0);
@@ -159,80 +280,41 @@ EKM_HD double m_rcp(double x) {
   return __builtin_isfinite(r) ? r : r0;  // x = 0, inf, NaN: keep the hardware answer (inf, 0, NaN)
 }
 EKM_HD double m_div(double a, double b) { return a * m_rcp(b); }
+// x - rint(x), exact for every finite x, |f| <= 0.5.  Contraction is switched off for this one subtraction: where x is a
+// product the compiler may otherwise fuse it into fma(a, b, -n) in one instantiation and not in another, and the two
+// passes of the kernels must round alike (tests/test_gpu_two_pass.py).
+EKM_HD double exp2_frac(double x, double n) {
+#pragma clang fp contract(off)
+  return x - n;
+}
 EKM_HD double m_exp2(double x) {
-  const double xc = __builtin_fmin(__builtin_fmax(x, -1100.0), 1100.0);
-  const double n = __builtin_rint(xc);
-  const double y = (xc - n) * 0.69314718055994530942;  // |y| <= 0.3466
-  double p = 2.4876145736304345e-05;                     // degree-8 interpolant of e^y at Chebyshev nodes
-  p = __builtin_fma(p, y, 0.00019915866953885213);
-  p = __builtin_fma(p, y, 0.0013888821718752312);
-  p = __builtin_fma(p, y, 0.008333266097830411);
-  p = __builtin_fma(p, y, 0.041666666890669196);
-  p = __builtin_fma(p, y, 0.16666666891046666);
-  p = __builtin_fma(p, y, 0.49999999999798606);
-  p = __builtin_fma(p, y, 0.9999999999797852);
-  p = __builtin_fma(p, y, 1.0);
-  const double r = __builtin_amdgcn_ldexp(p, (int)n);
-  return x != x ? x : r;
+  const double n = __builtin_rint(x);
+  double f = exp2_frac(x, n);         // NaN for +-inf
+  if (__builtin_isinf(x)) f = 0.0;    // 2^(+-inf) = inf / 0 through the saturated exponent
+  return __builtin_amdgcn_ldexp(exp2_poly(f), cvt_sat_i32(n));  // NaN stays NaN
 }
-// -DEKM_F64_LOG_TABLE: log2 by table: x = mant * 2^e, mant in [0.5, 1); j = the top 6 fraction bits of mant;
-// c_j = 1/(1 + (j + 0.5)/64), so r = 2*mant*c_j - 1 lies in (-1/129, 1/129) (one fma, exact) and
-// log2(x) = (e - 1) - log2(c_j) + log2(1 + r) with a degree-5 polynomial (truncation 5e-14 absolute); the 1-KiB table is
-// read-only device memory (gen/f64_log2_table.inc).  It drops the software reciprocal of the atanh argument (~55 instead
-// of ~110 clocks per logarithm) -- and measured in one process against the polynomial version (profiles/
-// r03_sweep_f64_log2_table.txt) it is NOT the default: the table reads go through the same vector-memory path as the
-// streams, so the HBM-bound kernels lose more (theta 3.39 -> 3.53 ms, theta_e 5.25 -> 5.58, the six-output pipeline
-// 16.7 -> 17.3) than the VALU-bound ones gain (wet-bulb 12.33 -> 12.19, bisection 15.9 -> 15.7).
-#if defined(EKM_F64_LOG_TABLE)
-static __device__ const double kLog2Tab[64][2] = {
-#include "gen/f64_log2_table.inc"
-};
-EKM_HD double m_log2_poly(double x);
 EKM_HD double m_log2(double x) {
-  const double mant = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
-  const int e = __builtin_amdgcn_frexp_exp(x);
-  const int j = (__double2hiint(mant) >> 14) & 63;
-  const double c2 = kLog2Tab[j][0], lj = kLog2Tab[j][1];
-  const double r = __builtin_fma(mant, c2, -1.0);
-  double p = 0.2 * 1.44269504088896340736;              // log2(1 + r)/r = (1 - r/2 + r^2/3 - r^3/4 + r^4/5)/ln 2
-  p = __builtin_fma(p, r, -0.25 * 1.44269504088896340736);
-  p = __builtin_fma(p, r, (1.0 / 3.0) * 1.44269504088896340736);
-  p = __builtin_fma(p, r, -0.5 * 1.44269504088896340736);
-  p = __builtin_fma(p, r, 1.44269504088896340736);
-  double res = __builtin_fma(p, r, lj + (double)(e - 1));
-  if (x == 0.0) res = -__builtin_inf();
-  if (x == __builtin_inf()) res = x;
-  if (x < 0.0 || x != x) res = __builtin_nan("");
-  return res;
-}
-EKM_HD double m_log2_poly(double x) {
-#else
-EKM_HD double m_log2(double x) {
-#endif
-#if defined(EKM_F64_LOG_SPLIT_SELECT)
-  int e = __builtin_amdgcn_frexp_exp(x);
-  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
-  if (m < 0.70710678118654752440) {
-    m *= 2.0;
-    e -= 1;
-  }
-#else
-  // x = m * 2^e with m in [0.7071, 1.4142): the exponent of x*sqrt(2) puts the split at sqrt(1/2)
-  const int e = __builtin_amdgcn_frexp_exp(x * 1.41421356237309504880) - 1;
-  const double m = __builtin_amdgcn_ldexp(x, -e);
-#endif
-  const double s = (m - 1.0) * m_rcp(m + 1.0);  // |s| <= 0.1716
-  const double z = s * s;
-  double p = 0.1180818033212343;                   // atanh(s)/s on z = s^2 in [0, 0.0295], degree 4
-  p = __builtin_fma(p, z, 0.14267525468490147);
-  p = __builtin_fma(p, z, 0.20000192337193154);
-  p = __builtin_fma(p, z, 0.3333333262373743);
-  p = __builtin_fma(p, z, 1.0000000000041798);
-  double r = __builtin_fma(p * s, 2.0 * 1.44269504088896340736, (double)e);
+  double r = log2_core(x);
   if (x == 0.0) r = -__builtin_inf();
   if (x == __builtin_inf()) r = x;
   if (x < 0.0 || x != x) r = __builtin_nan("");
   return r;
+}
+#define EKM_HAVE_FDOUBLE_FAST 1
+// fdouble: the same arithmetic, poison instead of fix-ups (see the type's comment above)
+EKM_HD fdouble m_rcp(fdouble x) {
+  const double r0 = __builtin_amdgcn_rcp(x.v);
+  return fdouble(__builtin_fma(r0, __builtin_fma(-x.v, r0, 1.0), r0));  // 0, inf, NaN, overflow: NaN
+}
+EKM_HD fdouble m_exp2(fdouble x) {
+  const double n = __builtin_rint(x.v);
+  return fdouble(__builtin_amdgcn_ldexp(exp2_poly(exp2_frac(x.v, n)), cvt_sat_i32(n)));  // +-inf: NaN
+}
+EKM_HD fdouble m_log2(fdouble x) {
+  const double r = log2_core(x.v);
+  // x <= 0, inf, NaN: poison through the high dword (one v_cmp_class_f64 + one v_cndmask_b32)
+  const bool good = __builtin_amdgcn_class(x.v, 0x080 | 0x100);  // +denormal | +normal
+  return fdouble(__hiloint2double(good ? __double2hiint(r) : 0x7ff80000, __double2loint(r)));
 }
 #endif
 EKM_HD double m_exp(double x) { return m_exp2(x * 1.44269504088896340736); }
@@ -248,10 +330,67 @@ EKM_HD double m_log(double x) { return log(x); }
 EKM_HD double m_pow(double x, double y) { return pow(x, y); }
 #endif
 
+#if defined(EKM_HAVE_FDOUBLE_FAST)
+EKM_HD fdouble m_div(fdouble a, fdouble b) { return a * m_rcp(b); }
+EKM_HD fdouble m_exp(fdouble x) { return m_exp2(x * fdouble(1.44269504088896340736)); }
+EKM_HD fdouble m_log(fdouble x) { return m_log2(x) * fdouble(0.69314718055994530942); }
+EKM_HD fdouble m_pow(fdouble x, fdouble y) { return m_exp2(y * m_log2(x)); }
+#else
+// fdouble where the fast primitives do not exist (host twin; -DEKM_F64_EXACT / -DEKM_F64_LIBM device builds): the plain
+// function of this build, poisoned under exactly the conditions under which the gfx950 composition above poisons, so
+// that the two-pass logic is what the CPU tests exercise (tests/test_hosttwin_two_pass.py).
+EKM_HD bool fd_rcp_ok(double x) { return x != 0.0 && __builtin_isfinite(x) && __builtin_isfinite(1.0 / x); }
+EKM_HD bool fd_log_ok(double x) { return x > 0.0 && x < __builtin_inf(); }
+EKM_HD fdouble fd_nan() { return fdouble(__builtin_nan("")); }
+EKM_HD fdouble m_rcp(fdouble x) { return fd_rcp_ok(x.v) ? fdouble(m_rcp(x.v)) : fd_nan(); }
+EKM_HD fdouble m_div(fdouble a, fdouble b) { return fd_rcp_ok(b.v) ? fdouble(m_div(a.v, b.v)) : fd_nan(); }
+EKM_HD fdouble m_exp2(fdouble x) { return __builtin_isinf(x.v) ? fd_nan() : fdouble(m_exp2(x.v)); }
+EKM_HD fdouble m_log2(fdouble x) { return fd_log_ok(x.v) ? fdouble(m_log2(x.v)) : fd_nan(); }
+EKM_HD fdouble m_exp(fdouble x) { return __builtin_isinf(x.v * 1.44269504088896340736) ? fd_nan() : fdouble(m_exp(x.v)); }
+EKM_HD fdouble m_log(fdouble x) { return fd_log_ok(x.v) ? fdouble(m_log(x.v)) : fd_nan(); }
+EKM_HD fdouble m_pow(fdouble x, fdouble y) {
+  return (fd_log_ok(x.v) && !__builtin_isinf(y.v * m_log2(x.v))) ? fdouble(m_pow(x.v, y.v)) : fd_nan();
+}
+#endif
+
+// xdouble: the plain primitives behind the wrapper's operators
+EKM_HD xdouble m_rcp(xdouble x) { return xdouble(m_rcp(x.v)); }
+EKM_HD xdouble m_exp2(xdouble x) { return xdouble(m_exp2(x.v)); }
+EKM_HD xdouble m_log2(xdouble x) { return xdouble(m_log2(x.v)); }
+#if defined(EKM_HAVE_FDOUBLE_FAST)
+EKM_HD xdouble m_div(xdouble a, xdouble b) { return a * m_rcp(b); }
+EKM_HD xdouble m_exp(xdouble x) { return m_exp2(x * xdouble(1.44269504088896340736)); }
+EKM_HD xdouble m_log(xdouble x) { return m_log2(x) * xdouble(0.69314718055994530942); }
+EKM_HD xdouble m_pow(xdouble x, xdouble y) { return m_exp2(y * m_log2(x)); }
+#else
+EKM_HD xdouble m_div(xdouble a, xdouble b) { return xdouble(m_div(a.v, b.v)); }
+EKM_HD xdouble m_exp(xdouble x) { return xdouble(m_exp(x.v)); }
+EKM_HD xdouble m_log(xdouble x) { return xdouble(m_log(x.v)); }
+EKM_HD xdouble m_pow(xdouble x, xdouble y) { return xdouble(m_pow(x.v, y.v)); }
+#endif
+
 template <class T>
 EKM_HD T m_sq(T x) {
   return x * x;
 }
+
+// a*b + c, a*b - c, c - a*b.  float / double: the plain expression, which the compiler contracts where it sees fit (the
+// fp32 kernels are what they were); fd64: ONE fused operation on the device, since its operators never contract.
+EKM_HD float m_fma(float a, float b, float c) { return a * b + c; }
+EKM_HD float m_fms(float a, float b, float c) { return a * b - c; }
+EKM_HD float m_fnma(float a, float b, float c) { return c - a * b; }
+EKM_HD double m_fma(double a, double b, double c) { return a * b + c; }
+EKM_HD double m_fms(double a, double b, double c) { return a * b - c; }
+EKM_HD double m_fnma(double a, double b, double c) { return c - a * b; }
+#if defined(__HIP_DEVICE_COMPILE__)
+EKM_FD fd64<F> m_fma(fd64<F> a, fd64<F> b, fd64<F> c) { return fd64<F>(__builtin_fma(a.v, b.v, c.v)); }
+EKM_FD fd64<F> m_fms(fd64<F> a, fd64<F> b, fd64<F> c) { return fd64<F>(__builtin_fma(a.v, b.v, -c.v)); }
+EKM_FD fd64<F> m_fnma(fd64<F> a, fd64<F> b, fd64<F> c) { return fd64<F>(__builtin_fma(-a.v, b.v, c.v)); }
+#else  // host twin: built with -ffp-contract=off, two roundings like its plain double
+EKM_FD fd64<F> m_fma(fd64<F> a, fd64<F> b, fd64<F> c) { return fd64<F>(a.v * b.v + c.v); }
+EKM_FD fd64<F> m_fms(fd64<F> a, fd64<F> b, fd64<F> c) { return fd64<F>(a.v * b.v - c.v); }
+EKM_FD fd64<F> m_fnma(fd64<F> a, fd64<F> b, fd64<F> c) { return fd64<F>(c.v - a.v * b.v); }
+#endif
 
 // min(|a|, |b|, |c|), NaN operands ignored (one v_min3_f32 with abs modifiers on the device)
 EKM_HD float m_min3abs(float a, float b, float c) {
@@ -264,6 +403,7 @@ EKM_HD double m_min3abs(double a, double b, double c) {
 // max of two values neither of which is NaN (one v_max_f32 on the device)
 EKM_HD float m_max(float a, float b) { return __builtin_fmaxf(a, b); }
 EKM_HD double m_max(double a, double b) { return __builtin_fmax(a, b); }
+EKM_FD fd64<F> m_max(fd64<F> a, fd64<F> b) { return fd64<F>(__builtin_fmax(a.v, b.v)); }
 
 // numpy.sign: -1 / 0 / +1, NaN stays NaN
 template <class T>
@@ -295,26 +435,26 @@ constexpr double LOG2_C1 = 9.25552433725897;  // log2(611.21)
 
 template <class T>
 EKM_HD T es_water(T t) {  // es_comp.py:133-134
-  return m_exp2((t - T(k::T0)) * m_rcp(t - T(k::C4W)) * T(k::C3W * k::LOG2E) + T(k::LOG2_C1));
+  return m_exp2(m_fma((t - T(k::T0)) * m_rcp(t - T(k::C4W)), T(k::C3W * k::LOG2E), T(k::LOG2_C1)));
 }
 
 template <class T>
 EKM_HD T es_ice(T t) {  // es_comp.py:137-138
-  return m_exp2((t - T(k::T0)) * m_rcp(t - T(k::C4I)) * T(k::C3I * k::LOG2E) + T(k::LOG2_C1));
+  return m_exp2(m_fma((t - T(k::T0)) * m_rcp(t - T(k::C4I)), T(k::C3I * k::LOG2E), T(k::LOG2_C1)));
 }
 
 // es and d(es)/dT for one phase from one reciprocal (es_comp.py:169-174)
 template <class T>
 EKM_HD void es_slope_water(T t, T& es, T& des) {
   const T r = m_rcp(t - T(k::C4W));
-  es = m_exp2((t - T(k::T0)) * r * T(k::C3W * k::LOG2E) + T(k::LOG2_C1));
+  es = m_exp2(m_fma((t - T(k::T0)) * r, T(k::C3W * k::LOG2E), T(k::LOG2_C1)));
   des = es * T(k::sw) * (r * r);
 }
 
 template <class T>
 EKM_HD void es_slope_ice(T t, T& es, T& des) {
   const T r = m_rcp(t - T(k::C4I));
-  es = m_exp2((t - T(k::T0)) * r * T(k::C3I * k::LOG2E) + T(k::LOG2_C1));
+  es = m_exp2(m_fma((t - T(k::T0)) * r, T(k::C3I * k::LOG2E), T(k::LOG2_C1)));
   des = es * T(k::si) * (r * r);
 }
 
@@ -329,7 +469,7 @@ EKM_HD T es_mixed(T t) {
   if (!EKM_ANY(!wat)) return es_water(t);  // the whole wave is at or above T0
   const T ew = es_water(t), ei = es_ice(t);
   const T a = m_sq((t - T(k::TI)) * T(1.0 / (k::T0 - k::TI)));
-  const T mid = a * (ew - ei) + ei;  // = a*ew + (1-a)*ei
+  const T mid = m_fma(a, ew - ei, ei);  // = a*ew + (1-a)*ei
   return ice ? ei : (wat ? ew : mid);
 }
 
@@ -352,8 +492,8 @@ EKM_HD void es_slope_mixed(T t, T& es, T& des) {
   const T a = m_sq(x * T(1.0 / (k::T0 - k::TI)));
   const T da = T(k::dalpha_c) * x;
   const T dif = ew - ei;
-  const T mid = a * dif + ei;                      // a*ew + (1-a)*ei
-  const T dmid = da * dif + (a * (dw - di) + di);  // da*ew + a*dw - da*ei + (1-a)*di
+  const T mid = m_fma(a, dif, ei);                      // a*ew + (1-a)*ei
+  const T dmid = m_fma(da, dif, m_fma(a, dw - di, di));  // da*ew + a*dw - da*ei + (1-a)*di
   es = ice ? ei : (wat ? ew : mid);
   des = ice ? di : (wat ? dw : dmid);
 }
@@ -378,13 +518,13 @@ EKM_HD void es_slope_phase(T t, T& es, T& des) {  // es_comp.py:82-106
 template <class T>
 EKM_HD T t_from_es(T es) {  // es_comp.py:109-130 (always the water formula)
   const T l = m_log2(es * T(1.0 / k::C1));  // v = ln(es/C1) = l*ln2, folded into the constants
-  return m_div(l * T(k::LN2 * k::C4W) - T(k::C3W * k::T0), l * T(k::LN2) - T(k::C3W));
+  return m_div(m_fms(l, T(k::LN2 * k::C4W), T(k::C3W * k::T0)), m_fms(l, T(k::LN2), T(k::C3W)));
 }
 
 // ---- humidity conversions ---------------------------------------------------
 template <class T>
 EKM_HD T e_from_q(T q, T p) {  // thermo.py:105-131
-  return m_div(p * q, T(k::eps) + T(k::q_c) * q);
+  return m_div(p * q, m_fma(T(k::q_c), q, T(k::eps)));
 }
 
 template <class T>
@@ -394,7 +534,7 @@ EKM_HD T e_from_w(T w, T p) {  // thermo.py:134-159
 
 template <class T>
 EKM_HD T q_from_e(T e, T p, T epsv) {  // thermo.py:162-196
-  T v = p + T(k::eps - 1) * e;
+  T v = m_fma(T(k::eps - 1), e, p);
   if ((p - e) < epsv) v = nan_v<T>();
   return m_div(T(k::eps) * e, v);
 }
@@ -428,7 +568,7 @@ EKM_HD T ws_slope(T p, T es, T des, T epsv) {
 // d(qs)/dT = eps*des*p/(p+es*(eps-1))^2, NaN where p-es < eps (thermo.py:418-467)
 template <class T>
 EKM_HD T qs_slope(T p, T es, T des, T epsv) {
-  T v = m_sq(p + es * T(k::eps - 1.0));
+  T v = m_sq(m_fma(es, T(k::eps - 1.0), p));
   if ((p - es) < epsv) v = nan_v<T>();
   return m_div(T(k::eps) * des * p, v);
 }
@@ -456,14 +596,14 @@ EKM_HD T t_on_dry_adiabat(T p, T t_def, T p_def) {  // thermo.py:892-920
 
 template <class T>
 EKM_HD T virtual_t(T t, T q) {  // thermo.py:738-764
-  return t * (T(1) + T(k::tv_c1) * q);
+  return t * m_fma(T(k::tv_c1), q, T(1));
 }
 
 template <int METHOD, class T>
 EKM_HD T lcl_t(T t, T td) {  // thermo.py:923-968
   if (METHOD == LCL_DAVIES)  // the two "- T0" of the reference's bracket folded into its constant: two fma
-    return td - (T(0.212 - (1.571e-3 - 4.36e-4) * k::T0) + T(1.571e-3) * td - T(4.36e-4) * t) * (t - td);
-  return T(56.0) + m_rcp(m_rcp(td - T(56)) + m_log(m_div(t, td)) * T(1.0 / 800));
+    return m_fnma(m_fnma(T(4.36e-4), t, m_fma(T(1.571e-3), td, T(0.212 - (1.571e-3 - 4.36e-4) * k::T0))), t - td, td);
+  return T(56.0) + m_rcp(m_fma(m_log(m_div(t, td)), T(1.0 / 800), m_rcp(td - T(56))));
 }
 
 // ---- equivalent potential temperature (thermo.py:1020-1323) ------------------
@@ -527,15 +667,18 @@ EKM_HD T ept_sat(T t, T p) {  // thermo.py:1042-1045
 // Horner with ascending coefficients (the namespace's polyval(x, c))
 template <class T>
 EKM_HD T poly2(T x, double c0, double c1, double c2) {
-  return T(c0) + (T(c1) + T(c2) * x) * x;
+  return m_fma(m_fma(T(c2), x, T(c1)), x, T(c0));
 }
 
-EKM_HD double wbpt_direct(double e) {  // thermo.py:1047-1053
-  const double x = e * (1.0 / 273.16);
-  const double a = 7.101574 + (-20.68208 + (16.11182 + (2.574631 + -5.205688 * x) * x) * x) * x;
-  const double b = 1.0 + (-3.552497 + (3.781782 + (-0.6899655 + -0.5929340 * x) * x) * x) * x;
+template <class T>
+EKM_HD T wbpt_direct_f64(T e) {  // thermo.py:1047-1053
+  const T x = e * T(1.0 / 273.16);
+  const T a = m_fma(m_fma(m_fma(m_fma(T(-5.205688), x, T(2.574631)), x, T(16.11182)), x, T(-20.68208)), x, T(7.101574));
+  const T b = m_fma(m_fma(m_fma(m_fma(T(-0.5929340), x, T(-0.6899655)), x, T(3.781782)), x, T(-3.552497)), x, T(1.0));
   return e - m_exp(m_div(a, b));
 }
+EKM_HD double wbpt_direct(double e) { return wbpt_direct_f64(e); }
+EKM_FD fd64<F> wbpt_direct(fd64<F> e) { return wbpt_direct_f64(e); }
 
 EKM_HD float wbpt_direct(float e) {
   const float x = e * float(1.0 / 273.16);
@@ -552,6 +695,7 @@ EKM_HD float wbpt_direct(float e) {
 // (0 -> no move, NaN -> NaN) when r is zero or unordered
 EKM_HD float bisect_step(float r, float dt) { return (r < 0.0f || r > 0.0f) ? __builtin_copysignf(dt, r) : r; }
 EKM_HD double bisect_step(double r, double dt) { return (r < 0.0 || r > 0.0) ? __builtin_copysign(dt, r) : r; }
+EKM_FD fd64<F> bisect_step(fd64<F> r, fd64<F> dt) { return fd64<F>(bisect_step(r.v, dt.v)); }
 
 // Moist-adiabat inversion by 12 fixed halvings (thermo.py:1055-1079), IFS variant, table-free statement (host twin;
 // the gfx950 kernels run t_on_ma_bisect_ifs_tab below, the same arithmetic with es_mixed read from an LDS table).
@@ -570,9 +714,9 @@ EKM_HD T t_on_ma_bisect_ifs_te(T te, T p) {
   for (int it = 0; it < 12; ++it) {
     const T es = es_mixed(t);
     esmax = m_max(esmax, es);
-    const T g = T(-k::K0_ifs * k::eps * k::LOG2E) * es * m_rcp((p + T(k::eps - 1) * es) * t);  // log2 of exp(-K0*qs/t)
+    const T g = T(-k::K0_ifs * k::eps * k::LOG2E) * es * m_rcp(m_fma(T(k::eps - 1), es, p) * t);  // log2 of exp(-K0*qs/t)
     dt *= T(0.5);
-    t += bisect_step(te * m_exp2(g) - t, dt);
+    t += bisect_step(m_fms(te, m_exp2(g), t), dt);
   }
   if ((p - esmax) < T(k::eps_default)) t = nan_v<T>();
   return t;
@@ -607,7 +751,7 @@ template <int METHOD, class T>
 EKM_HD T bisect_second(T es, T rt) {  // rt = 1/t_m
   if (METHOD == EPT_IFS) return T(-k::K0_ifs * k::eps * k::LOG2E) * es * rt;
   if (METHOD == EPT_BOLTON35) return T(-2675.0 * k::LOG2E) * rt;
-  return (T(-3036.0) * rt + T(1.78)) * T(k::LOG2E);
+  return m_fma(T(-3036.0), rt, T(1.78)) * T(k::LOG2E);
 }
 
 template <int METHOD, class T>
@@ -642,6 +786,15 @@ struct BisectEntry<METHOD, double> {
   }
 };
 
+template <int METHOD, bool F>
+struct BisectEntry<METHOD, fd64<F>> {  // the fp64 table read through the wrapper (same layout)
+  static constexpr int width = 1;
+  EKM_HD static void load(const fd64<F>* __restrict__ tab, int m, fd64<F>, fd64<F>& es, fd64<F>& a) {
+    es = tab[m];
+    a = fd64<F>(0.0);
+  }
+};
+
 // The 12 halvings on the table.  `e`: for ifs te = theta_e*(p/p0)^kappa, for the Bolton methods theta_e itself.
 // The reference's residual ept*exp(G_sat) - th_sat (thermo.py:1075) is divided by the positive th_sat/t:
 // r = e*exp2(g) - t has the same sign and costs ONE exp2 and one fma per step.  For ifs th_sat/t = (p0/p)^kappa is a
@@ -665,14 +818,14 @@ EKM_HD T t_on_ma_bisect_tab(T e, T p, const T* __restrict__ tab) {
 #endif
 #pragma unroll EKM_BISECT_UNROLL
   for (int it = 0; it < 12; ++it) {
-    int m = (int)(t * T(2048.0 / 120.0) + T(kBisectLattice / 2 + 0.5 - (k::T0 - 20) * (2048.0 / 120.0)));
+    int m = (int)m_fma(t, T(2048.0 / 120.0), T(kBisectLattice / 2 + 0.5 - (k::T0 - 20) * (2048.0 / 120.0)));
 #if !defined(__HIP_DEVICE_COMPILE__)
     if (!(t == t)) m = 0;  // v_cvt_i32_f32 turns NaN into 0; the host conversion is undefined
 #endif
     T es, a, g;
     BisectEntry<METHOD, T>::load(tab, m, t, es, a);
     esmax = m_max(esmax, es);
-    const T v = METHOD == EPT_IFS ? p + T(k::eps - 1) * es : p - es;
+    const T v = METHOD == EPT_IFS ? m_fma(T(k::eps - 1), es, p) : p - es;
     T rv;  // 1/v
     if (BisectEntry<METHOD, T>::width == 2) {
       rv = m_rcp(v);
@@ -686,12 +839,12 @@ EKM_HD T t_on_ma_bisect_tab(T e, T p, const T* __restrict__ tab) {
     } else {
       const T ws = T(k::eps) * es * rv;
       if (METHOD == EPT_BOLTON35)
-        g = kl + ws * (a - T(0.28) * kl);
+        g = m_fma(ws, m_fnma(T(0.28), kl, a), kl);
       else
-        g = a * ws * (T(1) + T(0.448) * ws) + T(k::kappa) * m_log2(v * T(1.0 / k::p0));
+        g = m_fma(a * ws, m_fma(T(0.448), ws, T(1)), T(k::kappa) * m_log2(v * T(1.0 / k::p0)));
     }
     dt *= T(0.5);
-    t += bisect_step(e * m_exp2(g) - t, dt);
+    t += bisect_step(m_fms(e, m_exp2(g), t), dt);
   }
   if ((p - esmax) < T(k::eps_default)) t = nan_v<T>();
   return t;
@@ -858,7 +1011,7 @@ EKM_HD PTerms<T> pterms(T p) {
   r.l = m_log2(p * T(1.0 / k::p0));
   r.p = p;
   r.thf = m_exp2(T(-k::kappa) * r.l);
-  r.dinv = T(0.1859e-5) * p + T(0.6512);
+  r.dinv = m_fma(T(0.1859e-5), p, T(0.6512));
   return r;
 }
 
@@ -891,7 +1044,7 @@ EKM_HD T t_on_ma_newton_ifs_core(T lte, T p, T dinv, const TeFn& te_fn, const Pp
     // A*eps*es/(v + A*eps*des).  v is NaN where p - es < eps, and es <= 0 (underflow) is the reference's 0*0/0.
     T v = p - es;
     if (v < T(k::eps_default) || !(es > T(0))) v = nan_v<T>();
-    const T g1 = (te - T(273.16)) - T(2675 * k::eps) * es * m_rcp(v + T(2675 * k::eps) * des);
+    const T g1 = m_fnma(T(2675 * k::eps) * es, m_rcp(m_fma(T(2675 * k::eps), des, v)), te - T(273.16));
     if (R.r1) tw = g1;
   }
   if (EKM_ANY(R.r2 || R.r3 || R.r4)) {
@@ -899,10 +1052,10 @@ EKM_HD T t_on_ma_newton_ifs_core(T lte, T p, T dinv, const TeFn& te_fn, const Pp
     const T k1 = poly2(pp, -53.737, 137.81, -38.5);
     const T k2 = poly2(pp, -0.384, 56.831, -4.392);
     const T k2m = k2 - T(1.21);
-    if (R.r2) tw = k1 - k2 * c_te;
-    if (R.r3) tw = (k1 - T(1.21)) - k2m * c_te;
+    if (R.r2) tw = m_fnma(k2, c_te, k1);
+    if (R.r3) tw = m_fnma(k2m, c_te, k1 - T(1.21));
     if (EKM_ANY(R.r4)) {
-      const T g4 = (k1 - T(2.66)) - k2m * c_te + T(0.58) * m_exp2(lam * lte);  // 0.58/c_te
+      const T g4 = m_fma(T(0.58), m_exp2(lam * lte), m_fnma(k2m, c_te, k1 - T(2.66)));  // 0.58/c_te
       if (R.r4) tw = g4;
     }
   }
@@ -916,16 +1069,16 @@ EKM_HD T t_on_ma_newton_ifs_core(T lte, T p, T dinv, const TeFn& te_fn, const Pp
   const T ltw = m_log2(tw * T(1.0 / 273.16));
   T es, des;
   es_slope_mixed(tw, es, des);
-  T v = p + T(k::eps - 1) * es;
+  T v = m_fma(T(k::eps - 1), es, p);
   if ((p - es) < T(k::eps_default)) v = nan_v<T>();
   const T r2 = m_rcp(v * tw);
   const T rv = r2 * tw;
   const T qr = T(k::eps) * es * r2;
-  const T ratio = m_exp2(lam * (ltw - lte) + T(k::lambda * k::K0_ifs * k::LOG2E) * qr);
+  const T ratio = m_exp2(m_fma(lam, ltw - lte, T(k::lambda * k::K0_ifs * k::LOG2E) * qr));
   const T dqs = (T(k::eps) * p) * des * (rv * rv);
-  const T den = T(1) + T(k::K0_ifs) * (dqs - qr);
+  const T den = m_fma(T(k::K0_ifs), dqs - qr, T(1));
   // f == 0 (tw -> inf) or f == inf make the reference's (f - c_te)/(f*dlnf) NaN; so does ratio = inf/NaN here
-  tw += ((T(1) - ratio) * T(1.0 / k::lambda)) * m_rcp(den) * tw;
+  tw = m_fma(((T(1) - ratio) * T(1.0 / k::lambda)) * m_rcp(den), tw, tw);
   if (tw <= T(0)) tw = nan_v<T>();  // thermo.py:1155
   return tw;
 }
@@ -1043,7 +1196,7 @@ EKM_HD T t_on_ma(T e, T p, Tie& tie) {  // thermo.py:1472-1509
     P.p = p;
     P.l = m_log2(p * T(1.0 / k::p0));
     P.thf = T(0);
-    P.dinv = T(0.1859e-5) * p + T(0.6512);
+    P.dinv = m_fma(T(0.1859e-5), p, T(0.6512));
     return t_on_ma_newton_ifs(e, P, tie);
   }
   return t_on_ma_newton<METHOD>(e, p, tie);

@@ -254,10 +254,7 @@ def test_dlpack_with_torch_as_foreign_producer_and_consumer(ek):
     assert "DLPACK_TORCH_OK" in r.stdout
 
 
-def test_bench_two_ranks_strong_scaling_on_one_device(ek):
-    """bench.py under torch.distributed.run with 2 ranks sharing this GPU: the N > 1 path on real hardware --
-    one field split by grid point (config 5's sharding), gloo barrier only, parity of rank 0's shard, the per-rank
-    report.  (Two ranks on one device share its bandwidth: the value is not a scaling measurement.)"""
+def _run_two_ranks(ek, extra, shared=True, levels="16"):
     import json
     import socket
     import subprocess
@@ -269,26 +266,82 @@ def test_bench_two_ranks_strong_scaling_on_one_device(ek):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
-           "--levels", "16", "--pmode", "level"]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
-    if ek.device_count() < 2:
-        # more ranks than GPUs without --allow-shared-device: the line says so and carries no value
-        r = subprocess.run(cmd[:-4] + ["--levels", "4", "--pmode", "level"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-        assert d["oversubscribed"] is True and d["value"] is None and d["hip_device_count"] == 1 and d["devices_used"] == [0]
+           "--levels", levels, "--sustain", "0.2"] + extra
+    if shared and ek.device_count() < 2:
         cmd.append("--allow-shared-device")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(line) == 1
-    d = json.loads(line[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    return json.loads(line[0])
+
+
+def test_bench_more_ranks_than_devices_reports_no_value(ek):
+    """More ranks than GPUs without --allow-shared-device: the line says so and carries no value."""
+    if ek.device_count() >= 2:
+        pytest.skip("needs a single-GPU box")
+    d = _run_two_ranks(ek, ["--pmode", "level"], shared=False, levels="4")
+    assert d["oversubscribed"] is True and d["value"] is None and d["hip_device_count"] == 1 and d["devices_used"] == [0]
+    assert d["value_from_kernel_ms"] is None
+
+
+@pytest.mark.parametrize("extra,cut", [
+    ([], "grid points"),                                  # the DEFAULT an 8-GPU node runs first: p a field, flat grid-point cut
+    (["--pmode", "level"], "levels"),
+    (["--pmode", "hybrid"], "levels"),
+    (["--workload", "geopotential"], "columns"),
+], ids=["field", "level", "hybrid", "geopotential-columns"])
+def test_bench_two_ranks_strong_scaling_on_one_device(ek, extra, cut):
+    """bench.py under torch.distributed.run with 2 ranks sharing this GPU: the N > 1 path on real hardware in every cut it
+    has -- ONE field split by grid point (config 5's default), on level boundaries (level vector / hybrid levels), by
+    columns (the column workloads) -- gloo barrier only, parity of rank 0's shard AND of the last rank's shard (whose first
+    point is not point 0), and the last rank's inputs equal to what the whole field holds at those points.  (Two ranks on
+    one device share its bandwidth: the value is not a scaling measurement.)"""
+    import argparse
+    import sys
+
+    d = _run_two_ranks(ek, extra)
+    nlev, inner = 16, 1800 * 3600
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["value_from_kernel_ms"] > 0
+    assert d["config"]["shard_cut"] == cut
     assert d["oversubscribed"] == (ek.device_count() < 2) and d["hip_device_count"] == ek.device_count()
     assert d["parity"]["ok"] and d["parity"]["nan_mismatch"] == 0
+    assert d["parity_last_rank"]["ok"] and d["parity_last_rank"]["rank"] == 1 and d["parity_last_rank"]["nan_mismatch"] == 0
     ranks = d["config"]["per_rank"]
-    assert [x["points"] for x in ranks] == [8 * 1800 * 3600] * 2 and all(x["kernel_ms"] > 0 for x in ranks)
+    assert sum(x["points"] for x in ranks) == nlev * inner and all(x["kernel_ms"] > 0 for x in ranks)
     assert all(x["hip_device_count"] >= 1 for x in ranks)
+    assert d["sustained"]["launches"] >= 5 and d["sustained"]["kernel_ms"] > 0
+    w = d["shard_window_last_rank"]
+    assert w["rank"] == 1
+    if cut == "columns":
+        assert w["global_col0"] >= inner // 2
+        return
+    # the whole field, generated here as ONE shard, must hold the last rank's values at the last rank's place
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    pmode = extra[1] if extra else "field"
+    args = argparse.Namespace(workload="full", pmode=pmode, dtype="f32", scaling="strong", levels=nlev)
+    sh = bench.plan_shard("full", pmode, "strong", 0, 1, nlev)
+    t, q, p, plev, hyb = bench.build_inputs(args, sh, 0, nlev, np.float32, 20260313)
+    g = w["global_index"]
+    assert g >= nlev * inner // 2 - inner, g  # rank 1's shard starts in the second half of the field
+    assert t.flat_slice(g, g + 8).to_host().tolist() == w["t"]
+    assert q.flat_slice(g, g + 8).to_host().tolist() == w["q"]
+    if pmode == "field":
+        pp = p.flat_slice(g, g + 8)
+    elif pmode == "level":
+        pp = plev.to_host()[g // inner]
+    else:
+        pp = ek.HybridPressure(hyb["Ah"].astype(np.float32), hyb["Bh"].astype(np.float32), hyb["sph"])
+    if pmode == "hybrid":  # the pipeline's theta on the whole level that holds the window
+        lev, col = g // inner, g % inner
+        th = ek.thermo.pipeline_full(t.to_host().reshape(nlev, inner), q.to_host().reshape(nlev, inner), pp)[0][lev, col:col + 8]
+    else:
+        th = ek.thermo.pipeline_full(t.flat_slice(g, g + 8), q.flat_slice(g, g + 8), pp)[0]
+        th = th.to_host() if hasattr(th, "to_host") else np.asarray(th)
+    assert np.asarray(th, np.float32).tolist() == w["out0"]
 
 
 def test_bench_measures_its_hbm_traffic_in_the_run(ek):
@@ -313,6 +366,12 @@ def test_bench_measures_its_hbm_traffic_in_the_run(ek):
     algorithmic = roof["bytes_per_point"] * roof["points_per_launch"]
     print(f"traffic {roof['traffic']:.4g} B vs algorithmic {algorithmic:.4g} B")
     assert abs(roof["traffic"] / algorithmic - 1.0) < 0.01
+    # the VALU side comes from a third child pass (SQ_INSTS_VALU, SQ_INSTS_VALU_TRANS_F32): executed instructions per point
+    assert roof["valu_source"].startswith("measured in this run"), roof["valu_source"]
+    c = roof["valu_counters"]
+    assert 100 < c["SQ_INSTS_VALU"] < 300 and 10 < c["SQ_INSTS_VALU_TRANS_F32"] < 40, c
+    assert 0.2 < roof["valu_frac"] < roof["frac"] < 1.0  # the six-output pipeline is HBM-bound: the HBM fraction is the larger
+    assert d["sustained"]["launches"] >= 3 and d["sustained"]["seconds"] >= 1.9 and 0.3 < d["sustained"]["frac"] < 1.0
 
 
 def test_concurrent_calls_from_several_threads(ek):

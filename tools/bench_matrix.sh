@@ -5,15 +5,15 @@ OUT=${1:?out.jsonl}; shift
 : > "$OUT"
 for wl in full p3 wetbulb wetbulb_bisect theta rh ept; do
   for pm in field level hybrid; do
-    timeout -k 10 120 python3 bench.py --workload $wl --pmode $pm --steps 20 --warmup 5 --no-cpu-baseline --traffic file "$@" >> "$OUT" 2>> "$OUT.err" || echo "{\"failed\": \"$wl $pm\"}" >> "$OUT"
+    timeout -k 10 120 python3 bench.py --workload $wl --pmode $pm --steps 20 --warmup 5 --no-cpu-baseline --traffic file --valu file --sustain 0 "$@" >> "$OUT" 2>> "$OUT.err" || echo "{\"failed\": \"$wl $pm\"}" >> "$OUT"
   done
 done
 for wl in wetbulb_bisect_bolton35 wetbulb_bisect_bolton39; do
-  timeout -k 10 120 python3 bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --traffic file "$@" >> "$OUT" 2>> "$OUT.err" || echo "{\"failed\": \"$wl\"}" >> "$OUT"
+  timeout -k 10 120 python3 bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --traffic file --valu file --sustain 0 "$@" >> "$OUT" 2>> "$OUT.err" || echo "{\"failed\": \"$wl\"}" >> "$OUT"
 done
-timeout -k 10 120 python3 bench.py --workload svp --steps 20 --warmup 5 --no-cpu-baseline --traffic file "$@" >> "$OUT" 2>> "$OUT.err"
-timeout -k 10 120 python3 bench.py --workload hybrid_levels --steps 20 --warmup 5 --traffic file "$@" >> "$OUT" 2>> "$OUT.err"
-timeout -k 10 120 python3 bench.py --workload geopotential --steps 20 --warmup 5 --traffic file "$@" >> "$OUT" 2>> "$OUT.err"
+timeout -k 10 120 python3 bench.py --workload svp --steps 20 --warmup 5 --no-cpu-baseline --traffic file --valu file --sustain 0 "$@" >> "$OUT" 2>> "$OUT.err"
+timeout -k 10 120 python3 bench.py --workload hybrid_levels --steps 20 --warmup 5 --traffic file --valu file --sustain 0 "$@" >> "$OUT" 2>> "$OUT.err"
+timeout -k 10 120 python3 bench.py --workload geopotential --steps 20 --warmup 5 --traffic file --valu file --sustain 0 "$@" >> "$OUT" 2>> "$OUT.err"
 python3 - "$OUT" <<'PY'
 import json, sys
 for ln in open(sys.argv[1]):

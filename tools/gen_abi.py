@@ -215,7 +215,10 @@ EKM_API int ekm_get_tuning(int* tiles_per_block, int* unroll);
  *   "hybrid_band_kb" [EKM_HYBRID_BAND_KB, 8192]  EKM_HYBRID_FULL: KiB of surface pressure per L2-resident band;
  *   "lev_per_wg"     [EKM_LEV_PER_WG, 0]         EKM_HYBRID_FULL: consecutive levels one workgroup walks (0 = by stream count);
  *   "table_tiles"    [EKM_TABLE_TILES, 8]        most tiles per workgroup for ops that keep an LDS table (bisection);
- *   "geo_chunk_levels" [EKM_GEO_CHUNK_LEVELS, all] levels per launch of the geopotential column scan. */
+ *   "geo_chunk_levels" [EKM_GEO_CHUNK_LEVELS, all] levels per launch of the geopotential column scan;
+ *   "f64_plain"        [EKM_F64_PLAIN, 0]          1: the fp64 map kernels redo EVERY lane with the plain-double primitives
+ *                      (IEEE special operands fixed up as libm does) instead of only the lanes whose fast first pass
+ *                      produced a non-finite output; same results, for tests and A/B timing. */
 EKM_API int ekm_set_tuning_param(const char* name, int value);
 
 /* ---- synthetic benchmark input, generated on the device (SURVEY.md 8d) ----

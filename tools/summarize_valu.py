@@ -26,28 +26,23 @@ def main():
     raw = {c: sum(v) / len(v) for c, v in agg[name].items()}
     valu, trans = raw["SQ_INSTS_VALU"] * 64 / npts, raw.get("SQ_INSTS_VALU_TRANS_F32", 0.0) * 64 / npts
     out = {"kernel": name[:160], "points_per_launch": npts, "kernel_ms_in_this_pass": bench["roofline"]["kernel_ms"],
-           "valu_instr_per_point": valu, "trans_instr_per_point": trans, "issue_units_per_point": valu + 3 * trans,
+           "valu_instr_per_point": valu, "trans_instr_per_point": trans, "issue_units_per_point_f32": valu + 3 * trans,
            "valu_active_over_wave_cycles": raw.get("SQ_ACTIVE_INST_VALU", 0) / raw["SQ_WAVE_CYCLES"],
            "wait_any_over_wave_cycles": raw.get("SQ_WAIT_ANY", 0) / raw["SQ_WAVE_CYCLES"],
            "wait_inst_any_over_wave_cycles": raw.get("SQ_WAIT_INST_ANY", 0) / raw["SQ_WAVE_CYCLES"], "raw": raw}
     cur = json.load(open(dst)) if os.path.exists(dst) else {}
     cur[key] = out
     json.dump(cur, open(dst, "w"), indent=1)
-    # what bench.py quotes the VALU roof from (profiles/valu_latest.json).  One issue unit = one plain VALU wave
-    # instruction at the rate the microbenchmark sustains (tools/microbench/valu_rates.hip, profiles/r03_valu_microbench.txt:
-    # v_fma_f32 935.4 G wave-instr/s x 64 lanes = 5.99e13 lane-ops/s); a transcendental (v_exp/v_log/v_rcp_f32: 295.2 G
-    # wave-instr/s) occupies the same issue port 3.17 x as long.
+    # what bench.py falls back to when its own in-run counter pass is unavailable (profiles/valu_latest.json): the executed
+    # wave-instructions per point by class; bench.py::valu_units weighs them
     args = bench["config"]
     bkey = f"{key.split('@')[0]}:{args['p_mode']}:{bench['dtype']}"
     lat = os.path.join(os.path.dirname(dst), "valu_latest.json")
     v = json.load(open(lat)) if os.path.exists(lat) else {}
-    v.setdefault("units_per_point", {})
-    v.update(peak_issue_units_per_s=5.99e13, trans_cost_units=3.17,
-             source="issue units per point = (SQ_INSTS_VALU - SQ_INSTS_VALU_TRANS_F32) + 3.17 x SQ_INSTS_VALU_TRANS_F32 per point from a "
-                    "rocprofv3 --pmc pass of this command (tools/profile_valu.sh); peak = the plain-VALU issue rate of "
-                    "tools/microbench/valu_rates.hip on this part (profiles/r03_valu_microbench.txt: 935.4 G wave-instr/s x 64 lanes), "
-                    "a transcendental costing 3.17 plain instructions (295.2 G wave-instr/s)")
-    v["units_per_point"][bkey] = round((valu - trans) + 3.17 * trans, 2)
+    v.setdefault("counts_per_point", {})
+    v["source"] = ("executed VALU wave-instructions x 64 lanes / points by class from rocprofv3 --pmc passes of bench.py "
+                   "(tools/profile_valu.sh)")
+    v["counts_per_point"][bkey] = {c: round(x * 64 / npts, 3) for c, x in raw.items() if c.startswith("SQ_INSTS_VALU")}
     json.dump(v, open(lat, "w"), indent=1)
     print(key, json.dumps({k: v for k, v in out.items() if k != "raw"}))
 
