@@ -6,8 +6,11 @@
 
 #include "thermo_math.hpp"
 
+#ifndef EKM_WAVES_PER_EU
+#define EKM_WAVES_PER_EU 1  // one macro for every kernel's launch bounds (a -DEKM_WAVES_PER_EU=N sweep reaches all of them)
+#endif
 #ifndef EKM_WAVES_PER_EU_DEFAULT
-#define EKM_WAVES_PER_EU_DEFAULT 1
+#define EKM_WAVES_PER_EU_DEFAULT EKM_WAVES_PER_EU
 #endif
 #ifndef EKM_P5_WAVES
 #define EKM_P5_WAVES 5

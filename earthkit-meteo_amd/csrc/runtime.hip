@@ -81,6 +81,8 @@ int device_cus(int dev) {
   return g_cus[dev];
 }
 
+static std::atomic<int> g_tuning_user_set{0};  // ekm_set_tuning was called (or EKM_TILES / EKM_UNROLL set): launch heuristics stand back
+int tuning_user_set() { return g_tuning_user_set.load(std::memory_order_relaxed); }
 int tuning_tiles_per_block() { return g_tiles_per_block.load(std::memory_order_relaxed); }
 int tuning_unroll() { return g_unroll.load(std::memory_order_relaxed); }
 
@@ -210,6 +212,20 @@ static int synth_levels_launch(int dev, void* stream, T* pl, uint32_t nlev) {
 
 }  // namespace ekm
 
+// ---- lookup tables of the table-driven ops (map_kernel.hpp::ensure_op_table) ----
+namespace ekm {
+typedef int (*table_prep_fn)(int dev);
+static std::mutex g_prep_mu;
+static std::vector<table_prep_fn>& prep_list() {
+  static std::vector<table_prep_fn> v;  // constructed on first use: registrations run during static initialisation
+  return v;
+}
+void register_table_prep(table_prep_fn fn) {
+  std::lock_guard<std::mutex> lk(g_prep_mu);
+  prep_list().push_back(fn);
+}
+}  // namespace ekm
+
 using namespace ekm;
 
 extern "C" {
@@ -310,150 +326,6 @@ int ekm_host_prefault(void* ptr, size_t bytes, int nthreads) {
   }
   work(0, per < bytes ? per : bytes);
   for (auto& th : pool) th.join();
-  return EKM_OK;
-}
-
-int ekm_host_memcpy(void* dst, const void* src, size_t bytes, int nthreads) {
-  // Host-to-host copy split over a few threads: one core moves ~10 GB/s, a PCIe Gen5 x16 direction ~55 GB/s, so
-  // staging a transfer through a pinned buffer needs several cores to keep the link busy.
-  if (bytes == 0) return EKM_OK;
-  if (!dst || !src) return set_error(EKM_ERR_ARG, "host_memcpy: null pointer");
-  if (nthreads < 1) nthreads = 1;
-  if (nthreads > 16) nthreads = 16;
-  if (bytes < (size_t)(1 << 20)) nthreads = 1;
-  char* d = static_cast<char*>(dst);
-  const char* s = static_cast<const char*>(src);
-  const size_t per = ((bytes + nthreads - 1) / nthreads + 4095) & ~size_t(4095);
-  std::vector<std::thread> pool;
-  for (int i = 1; i < nthreads; ++i) {
-    const size_t lo = (size_t)i * per;
-    if (lo >= bytes) break;
-    const size_t len = lo + per < bytes ? per : bytes - lo;
-    pool.emplace_back([d, s, lo, len] { memcpy(d + lo, s + lo, len); });
-  }
-  memcpy(d, s, per < bytes ? per : bytes);
-  for (auto& th : pool) th.join();
-  return EKM_OK;
-}
-
-// ---- staged transfers: pageable caller memory <-> device through pinned ring buffers --------------------------
-// Measured on the GPU box (tools/host_link_probe.py, profiles/r03_host_link_probe.txt): the link moves 57 GB/s per
-// direction and 96 GB/s in both at once from pinned memory; a pageable hipMemcpyAsync reaches that only for copies
-// of hundreds of MB (the runtime pins in place chunk by chunk) and drops to ~30 GB/s per direction for the 26-MB
-// slices the streamed path moves.  Here `nthreads` host threads each run a small pipeline over interleaved chunks:
-// memcpy into (out of) their own pinned slots at ~30 GB/s each, DMA on the caller's stream.
-namespace ekm {
-constexpr size_t kStageChunk = 8u << 20;
-constexpr int kStageMaxThreads = 8, kStageSlotsPerThread = 2;
-struct StageRing {
-  std::mutex mu;  // one job at a time per device and direction
-  void* buf[kStageMaxThreads * kStageSlotsPerThread] = {};
-  hipEvent_t ev[kStageMaxThreads * kStageSlotsPerThread] = {};
-  bool pending[kStageMaxThreads * kStageSlotsPerThread] = {};
-  bool init = false;
-};
-static StageRing g_stage[kMaxDev][2];
-
-struct StageChunk {
-  char* dst;
-  const char* src;
-  size_t len;
-};
-}  // namespace ekm
-
-int ekm_copy_staged(int dev, int to_device, int nseg, void* const* dst, const void* const* src, const size_t* bytes,
-                    void* stream, int nthreads) {
-  if (nseg <= 0) return EKM_OK;
-  if (!dst || !src || !bytes) return set_error(EKM_ERR_ARG, "copy_staged: null argument");
-  int rc = use_device(dev);
-  if (rc != EKM_OK) return rc;
-  if (nthreads < 1) nthreads = 1;
-  if (nthreads > kStageMaxThreads) nthreads = kStageMaxThreads;
-  std::vector<StageChunk> chunks;
-  for (int i = 0; i < nseg; ++i) {
-    if (bytes[i] == 0) continue;
-    if (!dst[i] || !src[i]) return set_error(EKM_ERR_ARG, "copy_staged: segment %d has a null pointer", i);
-    for (size_t off = 0; off < bytes[i]; off += kStageChunk)
-      chunks.push_back({static_cast<char*>(dst[i]) + off, static_cast<const char*>(src[i]) + off,
-                        bytes[i] - off < kStageChunk ? bytes[i] - off : kStageChunk});
-  }
-  if (chunks.empty()) return EKM_OK;
-  if ((size_t)nthreads > chunks.size()) nthreads = (int)chunks.size();
-  StageRing& ring = g_stage[dev][to_device ? 1 : 0];
-  std::lock_guard<std::mutex> lk(ring.mu);
-  if (!ring.init) {
-    for (int k = 0; k < kStageMaxThreads * kStageSlotsPerThread; ++k) {
-      EKM_HIP(hipHostMalloc(&ring.buf[k], kStageChunk, hipHostMallocDefault));
-      EKM_HIP(hipEventCreateWithFlags(&ring.ev[k], hipEventDisableTiming));
-    }
-    ring.init = true;
-  }
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  std::atomic<int> failed{0};
-  auto worker = [&](int w) {
-    if (hipSetDevice(dev) != hipSuccess) {
-      failed.store(1);
-      return;
-    }
-    auto ok = [&](hipError_t e) {
-      if (e != hipSuccess) failed.store(1);
-      return e == hipSuccess;
-    };
-    const int base = w * kStageSlotsPerThread;
-    if (to_device) {
-      int turn = 0;
-      for (size_t c = (size_t)w; c < chunks.size(); c += (size_t)nthreads, turn ^= 1) {
-        const int slot = base + turn;
-        if (ring.pending[slot] && !ok(hipEventSynchronize(ring.ev[slot]))) return;  // its last DMA must have left it
-        memcpy(ring.buf[slot], chunks[c].src, chunks[c].len);
-        if (!ok(hipMemcpyAsync(chunks[c].dst, ring.buf[slot], chunks[c].len, hipMemcpyHostToDevice, s))) return;
-        if (!ok(hipEventRecord(ring.ev[slot], s))) return;
-        ring.pending[slot] = true;
-      }
-    } else {
-      // two slots per thread: the DMA of chunk k+1 is in flight while chunk k is copied out to the caller's memory
-      long prev = -1;
-      int prev_slot = 0, turn = 0;
-      for (size_t c = (size_t)w; c < chunks.size(); c += (size_t)nthreads, turn ^= 1) {
-        const int slot = base + turn;
-        if (!ok(hipMemcpyAsync(ring.buf[slot], chunks[c].src, chunks[c].len, hipMemcpyDeviceToHost, s))) return;
-        if (!ok(hipEventRecord(ring.ev[slot], s))) return;
-        if (prev >= 0) {
-          if (!ok(hipEventSynchronize(ring.ev[prev_slot]))) return;
-          memcpy(chunks[prev].dst, ring.buf[prev_slot], chunks[prev].len);
-        }
-        prev = (long)c;
-        prev_slot = slot;
-      }
-      if (prev >= 0) {
-        if (!ok(hipEventSynchronize(ring.ev[prev_slot]))) return;
-        memcpy(chunks[prev].dst, ring.buf[prev_slot], chunks[prev].len);
-      }
-      for (int k = 0; k < kStageSlotsPerThread; ++k) ring.pending[base + k] = false;
-    }
-  };
-  std::vector<std::thread> pool;
-  for (int w = 1; w < nthreads; ++w) pool.emplace_back(worker, w);
-  worker(0);
-  for (auto& th : pool) th.join();
-  if (failed.load()) {
-    hipError_t e = hipGetLastError();
-    return set_error(EKM_ERR_HIP, "copy_staged: %s", e != hipSuccess ? hipGetErrorString(e) : "a staged transfer failed");
-  }
-  return EKM_OK;
-}
-
-int ekm_host_register(void* ptr, size_t bytes) {
-  if (!ptr || bytes == 0) return set_error(EKM_ERR_ARG, "host_register: null pointer or empty range");
-  int rc = probe();
-  if (rc != EKM_OK) return rc;
-  EKM_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
-  return EKM_OK;
-}
-
-int ekm_host_unregister(void* ptr) {
-  if (!ptr) return EKM_OK;
-  EKM_HIP(hipHostUnregister(ptr));
   return EKM_OK;
 }
 
@@ -570,11 +442,27 @@ int ekm_event_elapsed_ms(int dev, void* start, void* stop, float* ms) {
   return EKM_OK;
 }
 
+// ---- lookup tables of the table-driven ops (map_kernel.hpp::ensure_op_table) ----
+
+int ekm_prepare_tables(int dev) {
+  std::vector<ekm::table_prep_fn> fns;
+  {
+    std::lock_guard<std::mutex> lk(ekm::g_prep_mu);
+    fns = ekm::prep_list();
+  }
+  for (ekm::table_prep_fn fn : fns) {
+    const int rc = fn(dev);
+    if (rc != EKM_OK) return rc;
+  }
+  return EKM_OK;
+}
+
 int ekm_set_tuning(int tiles_per_block, int unroll) {
   if (tiles_per_block < 0 || tiles_per_block > 65536 || unroll < 0 || unroll > 2)
     return set_error(EKM_ERR_ARG, "set_tuning: tiles_per_block in [1,65536], unroll in {1,2} (0 keeps)");
   if (tiles_per_block) g_tiles_per_block.store(tiles_per_block);
   if (unroll) g_unroll.store(unroll);
+  if (tiles_per_block || unroll) g_tuning_user_set.store(1);
   return EKM_OK;
 }
 

@@ -133,21 +133,26 @@ class _Plan:
         self.n = int(np.prod(self.shape, dtype=np.int64))
 
 
-_KDLROCM = 10
+_KDLCPU, _KDLROCM, _KDLROCMHOST = 1, 10, 11
 
 
 def _adopt_foreign(args):
-    """Arrays of another ROCm library (anything whose `__dlpack_device__()` says kDLROCM: a torch / cupy device
-    tensor) are taken over through DLPack -- zero copy, the producer ordered before our stream -- exactly as if the
-    caller had written `ekm_hip.from_dlpack(x)`: the reference selects its backend from the input type in the same way
-    (`array_namespace(*inputs)`, thermo/array/thermo.py:826, es_comp.py:73).  Returns the arguments with such arrays
-    wrapped, and the name of the producing library when EVERY array argument came from that one library (else None)."""
-    mods, plain, out = set(), False, []
+    """Arrays of another array library are taken as the reference takes them: it selects its backend from the input type
+    (`array_namespace(*inputs)`, thermo/array/thermo.py:826, es_comp.py:73) and returns that type.
+      * a ROCm array (`__dlpack_device__()` says kDLROCM: a torch / cupy device tensor) is taken over through DLPack --
+        zero copy, the producer ordered before our stream -- exactly as if the caller had written
+        `ekm_hip.from_dlpack(x)`;
+      * a HOST array of a foreign library (kDLCPU / kDLROCMHost: a torch CPU tensor) is viewed as a NumPy array through
+        DLPack (zero copy; `np.asarray` where the producer refuses the export, e.g. a tensor that requires grad).
+    Returns the arguments with such arrays replaced, and (library name, "device" | "host") when EVERY array argument came
+    from that one library and one side (else None): the results then go back through that library."""
+    mods, sides, plain, out = set(), set(), False, []
     for a in args:
         dd = None
         if not isinstance(a, (DeviceArray, HybridPressure, np.ndarray, np.generic, bool, int, float, list, tuple)):
             dd = getattr(a, "__dlpack_device__", None)
-        if dd is not None and hasattr(a, "__dlpack__") and dd()[0] == _KDLROCM:
+        kind = dd()[0] if dd is not None and hasattr(a, "__dlpack__") else None
+        if kind == _KDLROCM:
             from .dlpack import from_dlpack
 
             try:
@@ -157,22 +162,45 @@ def _adopt_foreign(args):
                     raise
                 out.append(from_dlpack(a.contiguous()))
             mods.add(type(a).__module__.split(".")[0])
+            sides.add("device")
+        elif kind in (_KDLCPU, _KDLROCMHOST):
+            try:
+                out.append(np.from_dlpack(a))
+            except Exception:  # the producer refuses (requires grad, exotic dtype ...): its own conversion
+                out.append(np.asarray(a.detach() if hasattr(a, "detach") else a))
+            mods.add(type(a).__module__.split(".")[0])
+            sides.add("host")
         else:
             out.append(a)
             plain = plain or isinstance(a, (DeviceArray, HybridPressure)) or np.ndim(a) > 0
-    return out, (mods.pop() if len(mods) == 1 and not plain else None)
+    one = len(mods) == 1 and len(sides) == 1 and not plain
+    return out, ((mods.pop(), sides.pop()) if one else None)
 
 
-def _hand_back(results, module):
-    """Results for a caller whose inputs all came from one foreign library: through that library's own
-    `from_dlpack` (zero copy; it passes its current stream, which is then ordered after our kernel).  The library
-    is looked up among the modules the CALLER has imported -- the product never imports it."""
+def _hand_back(results, foreign):
+    """Results for a caller whose inputs all came from one foreign library: through that library's own `from_dlpack`
+    (zero copy; for device arrays it passes its current stream, which is then ordered after our kernel), NumPy scalars
+    through its `asarray`.  The library is looked up among the modules the CALLER has imported -- the product never
+    imports it; a library without these entry points gets our own types back."""
     import sys
 
-    fn = getattr(sys.modules.get(module), "from_dlpack", None)
+    module, side = foreign
+    mod = sys.modules.get(module)
+    fn = getattr(mod, "from_dlpack", None)
     if fn is None:
         return results
-    return tuple(fn(r) if isinstance(r, DeviceArray) else r for r in results)
+    if side == "device":
+        return tuple(fn(r) if isinstance(r, DeviceArray) else r for r in results)
+    out = []
+    for r in results:
+        if isinstance(r, np.ndarray) and r.ndim > 0:
+            if not r.flags.writeable:
+                r = r.copy()
+            out.append(fn(r))
+        else:
+            conv = getattr(mod, "asarray", None) or getattr(mod, "as_tensor", None)
+            out.append(conv(r) if conv is not None else r)
+    return tuple(out)
 
 
 def run(name, args, ints=(), eps=None, dtype=None):
@@ -222,10 +250,9 @@ def leading_axis_bounds(n0, nshards):
 
 _streams = {}
 _streams_lock = threading.Lock()
-_STAGED = os.environ.get("EKM_STAGED", "0") == "1"  # streamed path: transfers through the library's pinned staging ring instead
 _MAX_LANES = 8            # slices in flight per GPU when memory allows (upload of one overlaps download of another)
 _MIN_SLICE_BYTES = 16 << 20  # do not cut finer than this: small copies waste PCIe bandwidth
-_BLOCK_OVERHEAD = (1 << 20) + 16 * (20 << 10)  # worst-case rounding + stagger padding of one device block
+_BLOCK_OVERHEAD = 1 << 20  # worst-case rounding of one device block (the allocator's buckets are multiples of 1 MiB)
 
 
 def _lane_stream(dev, slot):
@@ -273,7 +300,7 @@ def plan_slices(rows, row_bytes, budget, max_lanes=_MAX_LANES, min_slice=_MIN_SL
         a short pipeline ramp; the lanes recycle their device blocks);
       * it does not fit: as many lanes as the budget allows with slices of at least `min_slice` (8, 4), at
         least two (double buffering) whatever the slice size; None if two single-row slices do not fit.
-    `overhead`: device bytes every in-flight slice costs on top of its rows (allocator rounding and stagger)."""
+    `overhead`: device bytes every in-flight slice costs on top of its rows (allocator rounding)."""
     total = rows * row_bytes
     if total == 0:
         return 1, 1
@@ -293,80 +320,20 @@ def plan_slices(rows, row_bytes, budget, max_lanes=_MAX_LANES, min_slice=_MIN_SL
     return None
 
 
-_PAGE = 4096
-# Streamed path, route of the transfers.  Measured on the GPU box (tools/host_path_rate.py, profiles/r03_host_path_rate.txt;
-# link capacity: tools/host_link_probe.py, profiles/r03_host_link_probe.txt -- 57 GB/s per direction, 96 GB/s both ways):
-#   plain pageable hipMemcpyAsync per operand (default)          P3 on 8 levels 57 GB/s both directions together
-#   EKM_STAGED=1    through the library's pinned ring            50 GB/s (8 host threads busy; a 78-MB job is mostly ramp)
-#   EKM_PIN_HOST=1  caller memory pinned in place, slice-wise    40 GB/s (registering FRESH result pages is slow and
-#                                                                 stalls the DMA queue while it runs)
-#   both            inputs pinned in place, results through the ring   43-54 GB/s
-# so none of these is the default; they stay selectable and tested.  What DOES pay is where the RESULTS live: in pinned
-# host memory from a recycling pool (device.pinned_empty; `_PINNED_OUT` below, the default) the downloads are plain DMAs
-# -- P3 on 8 levels 61 -> 80 GB/s, on 32 levels 74 -> 85 (87 with the caller's inputs in pinned memory too).
-_PINNED = os.environ.get("EKM_PIN_HOST", "0") == "1"
-_PINNED_OUT = os.environ.get("EKM_PINNED_RESULTS", "1") != "0"   # results of big NumPy calls in pooled pinned memory
-_PINNED_OUT_BYTES = int(os.environ.get("EKM_PINNED_RESULTS_BYTES", str(8 << 30)))
-
-
-class _Pinner:
-    """Pins caller-owned host memory in place (hipHostRegister), one slice ahead of the transfers, and moves data
-    to / from it.
-
-    Measured on the GPU box (tools/host_link_probe.py, profiles/r03_host_link_probe.txt): from pinned memory the
-    link moves 57 GB/s per direction and 96 GB/s in both at once with no host CPU work, and pinning costs 10 ms per
-    GB (105 GB/s) -- faster than the link, so a pinner thread stays ahead of the copies.  A pageable
-    hipMemcpyAsync of a 26-MB slice reaches ~30 GB/s per direction (the runtime pins and unpins around every copy).
-    Only the whole pages INSIDE a slice's byte range are pinned, so the pieces of neighbouring slices never overlap;
-    the two sub-page ends of a range travel as tiny pageable copies.  Pinning also creates the pages of fresh result
-    arrays.  Any registration that fails simply leaves that range pageable: the copies still work."""
-
-    def __init__(self):
-        self.pinned = set()
-        self.lock = threading.Lock()
-
-    @staticmethod
-    def body(ptr, nbytes):
-        lo, hi = -(-ptr // _PAGE) * _PAGE, (ptr + nbytes) // _PAGE * _PAGE
-        return (lo, hi) if hi - lo >= (1 << 20) else None
-
-    def pin(self, ptr, nbytes):
-        b = self.body(ptr, nbytes)
-        if b is not None and _ffi.lib().ekm_host_register(b[0], b[1] - b[0]) >= 0:
-            with self.lock:
-                self.pinned.add(b)
-
-    def unpin(self, ptr, nbytes):
-        b = self.body(ptr, nbytes)
-        with self.lock:
-            if b not in self.pinned:
-                return
-            self.pinned.discard(b)
-        _ffi.lib().ekm_host_unregister(b[0])
-
-    def unpin_all(self):
-        with self.lock:
-            left, self.pinned = list(self.pinned), set()
-        for b in left:
-            _ffi.lib().ekm_host_unregister(b[0])
-
-    def _parts(self, ptr, nbytes):
-        b = self.body(ptr, nbytes)
-        with self.lock:
-            ok = b in self.pinned
-        if not ok:
-            return [(0, nbytes)]
-        return [(o, n) for o, n in ((0, b[0] - ptr), (b[0] - ptr, b[1] - b[0]), (b[1] - ptr, ptr + nbytes - b[1])) if n]
-
-    def h2d(self, dev, dptr, hptr, nbytes, stream):
-        lib = _ffi.lib()
-        for off, n in self._parts(hptr, nbytes):
-            _ffi.check(lib.ekm_h2d(dev, dptr + off, hptr + off, n, stream))
-
-    def d2h(self, dev, hptr, dptr, nbytes, stream):
-        lib = _ffi.lib()
-        for off, n in self._parts(hptr, nbytes):
-            _ffi.check(lib.ekm_d2h(dev, hptr + off, dptr + off, n, stream))
+# Streamed path: plain hipMemcpyAsync per operand, and the RESULTS of big calls in pinned host memory from a recycling pool
+# (device.pinned_empty) so that the downloads are plain DMAs: P3 on 8 levels 61 -> 80 GB/s, on 32 levels 74 -> 85 GB/s both
+# directions together (profiles/r03_host_path_rate.txt; link capacity 57 GB/s per direction, 96 both ways:
+# profiles/r03_host_link_probe.txt).  Three other routes were built, tested bit-equal and measured in round 3 -- transfers
+# staged through a ring of pinned buffers (44-57 GB/s in the pipeline), the caller's memory pinned in place slice by slice
+# (31-44), both together (43-54) -- and removed in round 4: none came near the default.
+# Pinned memory is page-locked: it cannot be swapped and counts against container and memlock limits.  So the pool is
+# bounded -- a call's results go there only up to EKM_PINNED_RESULTS_BYTES (default 4 GiB per call), callers may hold
+# at most EKM_PINNED_LIVE_BYTES (4 GiB) of such results alive at once and at most EKM_PINNED_CACHE_BYTES (1 GiB) stay
+# cached after they are dropped; beyond that results are ordinary arrays (prefaulted from a helper thread).  A result in
+# pooled memory does not own its data (`.base` is a ctypes buffer; `ndarray.resize` refuses): EKM_PINNED_RESULTS=0 turns
+# the pool off.
+_PINNED_OUT = os.environ.get("EKM_PINNED_RESULTS", "1") != "0"
+_PINNED_OUT_BYTES = int(os.environ.get("EKM_PINNED_RESULTS_BYTES", str(4 << 30)))
 
 
 def _run_streamed(name, args, ints, eps, dtype, devs):
@@ -402,7 +369,7 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
     blocks = [b for b in leading_axis_bounds(shape[0], len(devs)) if b[1] > b[0]]
     plans = []
     for dev, (lo, hi) in zip(devs, blocks):
-        # every device block of a slice is rounded up to 1 MiB and carries the stagger padding (device._Allocation)
+        # every device block of a slice is rounded up to 1 MiB (device._Allocation)
         nblocks = sum(spans) + nout
         pl = plan_slices(hi - lo, max(row_bytes, 1), stream_budget_bytes(dev), overhead=nblocks * _BLOCK_OVERHEAD)
         if pl is None:
@@ -429,33 +396,16 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
         for sl in mine:
             ready[sl] = threading.Event()
 
-    # Pin the caller's arrays and the result arrays in place, slice by slice, ahead of the transfers (a pinner thread,
-    # at most `depth + 2` slices ahead per GPU; a finished slice is unpinned by the downloader).  The operands that
-    # qualify: C-contiguous, already in the compute dtype, spanning the leading axis.
-    pinner = _Pinner() if _PINNED else None  # with _STAGED too: inputs pinned in place, results through the staging ring
-    pin_in = [h for h, sp in zip(host, spans) if sp and h.flags.c_contiguous and h.dtype == cdtype] if pinner else []
-    pin_out = outs if pinner and out_dtype == cdtype and not _STAGED and not pinned_outs else []  # (pool blocks are pinned already)
-    pin_ahead = [threading.Semaphore(depth + 2) for depth, _n in plans]
-
-    def slice_ranges(lo, hi):
-        return [(a[lo:hi].ctypes.data, a[lo:hi].nbytes) for a in pin_in + pin_out]
-
     def toucher():
-        # make the result pages exist slice by slice, in the order the transfers will need them, all GPUs interleaved:
-        # by pinning them (which also pins the inputs), else by faulting them in
+        # make the result pages of ordinary (non-pooled) result arrays exist slice by slice, in the order the transfers
+        # will need them, all GPUs interleaved
         try:
             lib = _ffi.lib()
             for k in range(max(len(m) for m in slices)):
-                for d, mine in enumerate(slices):
+                for mine in slices:
                     if k < len(mine):
                         lo, hi = mine[k]
-                        if pinner is not None:
-                            pin_ahead[d].acquire()
-                            if errors:
-                                return
-                            for ptr, nb in slice_ranges(lo, hi):
-                                pinner.pin(ptr, nb)
-                        if not pin_out and not pinned_outs and outs[0][lo:hi].nbytes >= _PRETOUCH_BYTES // 8:
+                        if not pinned_outs and outs[0][lo:hi].nbytes >= _PRETOUCH_BYTES // 8:
                             for o in outs:
                                 lib.ekm_host_prefault(o[lo:hi].ctypes.data, o[lo:hi].nbytes, 4)
                         ready[mine[k]].set()
@@ -476,8 +426,6 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
                 slots.acquire()  # at most `depth` slices resident on the device
                 if errors:
                     break
-                if pinner is not None:
-                    ready[(lo, hi)].wait()  # its host ranges are pinned
                 t1 = _time.perf_counter()
                 set_stream(_lane_stream(dev, k % depth))
                 # operands that span the leading axis get the matching slice; everything else is passed as
@@ -486,8 +434,7 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
                 # slices differ by one row: every slice's device blocks are sized for the LONGEST slice, so a lane takes
                 # back exactly the blocks it released (same bucket) and the footprint stays lanes x slice, live + cached
                 handoff.put(((lo, hi), _submit(name, part, ints, eps, dtype, host_out=[o[lo:hi] for o in outs],
-                                               reserve_rows=(hi - lo, most), staged=_STAGED, copier=pinner,
-                                               staged_down=_STAGED and not pinned_outs)))
+                                               reserve_rows=(hi - lo, most))))
                 if trace is not None:
                     trace.append(("up", k, t0, t1, _time.perf_counter()))
         except BaseException as exc:  # surfaced in the calling thread
@@ -515,10 +462,6 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
                         if trace is not None:
                             trace.append(("down", sl[0], t0, t1, _time.perf_counter()))
                 finally:
-                    if pinner is not None:
-                        for ptr, nb in slice_ranges(*sl):
-                            pinner.unpin(ptr, nb)
-                        pin_ahead[d].release()
                     slots.release()
         except BaseException as exc:
             errors.append(exc)
@@ -534,8 +477,6 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
         th.start()
     for th in threads:
         th.join()
-    if pinner is not None:
-        pinner.unpin_all()  # (only after an error: every finished slice has been unpinned already)
     if errors:
         raise errors[0]
     if trace is not None:  # EKM_TRACE_STREAM=1: when each slice waited / moved (ms since the first event)
@@ -548,7 +489,7 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
 class _Pending:
     """One submitted launch: device results (and the temporaries its operands live in) not yet collected."""
 
-    __slots__ = ("plan", "results", "temps", "host_out", "internal_out", "toucher", "stream", "staged", "copier", "keep")
+    __slots__ = ("plan", "results", "temps", "host_out", "internal_out", "toucher", "stream")
 
 
 def _reserved(nbytes, reserve_rows):
@@ -564,22 +505,7 @@ def _run_single(name, args, ints=(), eps=None, dtype=None, host_out=None, touche
     return _collect(_submit(name, args, ints, eps, dtype, host_out, toucher))
 
 
-_STAGE_THREADS = int(os.environ.get("EKM_STAGE_THREADS", "4"))  # host copy threads per direction of a staged transfer
-
-
-def _copy_staged(dev, to_device, pairs, stream):
-    """One pipelined job through the library's pinned staging ring (ekm_copy_staged): `pairs` = [(dst, src, nbytes)]."""
-    n = len(pairs)
-    if not n:
-        return
-    dst = (C.c_void_p * n)(*[p[0] for p in pairs])
-    src = (C.c_void_p * n)(*[p[1] for p in pairs])
-    nb = (C.c_size_t * n)(*[p[2] for p in pairs])
-    _ffi.check(_ffi.lib().ekm_copy_staged(dev, int(to_device), n, dst, src, nb, stream, _STAGE_THREADS))
-
-
-def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=None, reserve_rows=None, staged=False,
-            copier=None, staged_down=None):
+def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=None, reserve_rows=None):
     """Upload what lives on the host, launch, return without waiting for the kernel (the uploads themselves are
     synchronous copies on the current stream).  `reserve_rows` = (rows of this slice, rows of the longest slice):
     field-sized device blocks are reserved at the longest slice's size (streamed path)."""
@@ -593,8 +519,6 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
 
     temps = []  # device buffers owned by this call
     operands = []
-    uploads = []  # staged: (device pointer, host pointer, bytes, the host array kept alive)
-    keep = []     # host arrays an asynchronous upload is still reading
     lds_bytes = 0
     internal_out = False  # host_out allocated here (compute dtype) rather than supplied by the caller
     if not plan.on_device and host_out is None and plan.n * plan.dtype.itemsize >= _PRETOUCH_BYTES:
@@ -643,24 +567,11 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
                 cls = (_ffi.FIELD, 0, 0)
             hc = np.ascontiguousarray(h, dtype=plan.dtype)
             cap = _reserved(hc.size * plan.dtype.itemsize, reserve_rows)
-            if copier is not None and hc.nbytes >= (1 << 20):
-                # streamed path, caller memory pinned in place: an asynchronous DMA, ordered before the kernel on this
-                # stream (`hc` is kept alive with the launch until its results have been collected)
-                darr = DeviceArray.empty(hc.shape, plan.dtype, dev, capacity=cap)
-                copier.h2d(dev, darr.on(stream), hc.ctypes.data, hc.nbytes, stream)
-                keep.append(hc)
-            elif staged and hc.nbytes >= (1 << 20):
-                # streamed path: all host operands of the slice go up as ONE pipelined job through pinned buffers
-                darr = DeviceArray.empty(hc.shape, plan.dtype, dev, capacity=cap)
-                uploads.append((darr.on(stream), hc.ctypes.data, hc.nbytes, hc))
-            else:
-                darr = DeviceArray.from_host(hc, device=dev, capacity=cap)
+            darr = DeviceArray.from_host(hc, device=dev, capacity=cap)
             temps.append(darr)
         # .on(stream): an input last used on another stream makes this stream wait for that work (device-side)
         operands.append(_ffi.Operand(darr.on(stream), cls[0], 0, cls[1], cls[2]))
 
-    if uploads:
-        _copy_staged(dev, True, [u[:3] for u in uploads], stream)  # returns once the caller's memory has been read
     results = [DeviceArray.empty(plan.shape, plan.dtype, dev, capacity=_reserved(plan.n * plan.dtype.itemsize, reserve_rows))
                for _ in outs]
     cargs = [dev, stream] + [C.byref(o) for o in operands] + [int(v) for v in ints]
@@ -671,8 +582,6 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
     pend = _Pending()
     pend.plan, pend.results, pend.temps, pend.host_out = plan, results, temps, host_out
     pend.internal_out, pend.toucher, pend.stream = internal_out, toucher, stream
-    pend.staged = staged if staged_down is None else staged_down  # results through the staging ring (not into pinned memory)
-    pend.copier, pend.keep = copier, keep
     return pend
 
 
@@ -690,27 +599,6 @@ def _collect(pend):
     if toucher is not None:
         toucher.join()
     host = []
-    if pend.copier is not None and not pend.staged and host_out is not None and all(
-            h.dtype == plan.dtype and h.flags.c_contiguous and h.size == r.size for h, r in zip(host_out, results)):
-        # streamed path, result memory pinned in place: asynchronous DMAs, one wait for the whole slice
-        for h, r in zip(host_out, results):
-            pend.copier.d2h(plan.device, h.ctypes.data, r.on(pend.stream), r.nbytes, pend.stream)
-        _ffi.check(_ffi.lib().ekm_stream_sync(plan.device, pend.stream))
-        for r in results:
-            r.free()
-        for t in temps:
-            t.free()
-        return tuple(host_out)
-    if pend.staged and host_out is not None and all(
-            h.dtype == plan.dtype and h.flags.c_contiguous and h.size == r.size for h, r in zip(host_out, results)):
-        # streamed path: all results of the slice come down as ONE pipelined job through pinned buffers
-        _copy_staged(plan.device, False, [(h.ctypes.data, r.on(pend.stream), r.nbytes) for h, r in zip(host_out, results)],
-                     pend.stream)
-        for r in results:
-            r.free()
-        for t in temps:
-            t.free()
-        return tuple(host_out)
     for k, r in enumerate(results):
         if host_out is not None and host_out[k].dtype == plan.dtype and host_out[k].flags.c_contiguous:
             h = r.to_host(out=host_out[k])  # straight into the caller's slice

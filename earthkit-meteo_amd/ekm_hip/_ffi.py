@@ -55,8 +55,6 @@ def _signatures():
         "ekm_malloc": ([i, sz, pvp], i), "ekm_free": ([i, vp], i),
         "ekm_host_alloc": ([sz, pvp], i), "ekm_host_free": ([vp], i),
         "ekm_host_prefault": ([vp, sz, i], i),
-        "ekm_copy_staged": ([i, i, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), vp, i], i),
-        "ekm_host_memcpy": ([vp, vp, sz, i], i), "ekm_host_register": ([vp, sz], i), "ekm_host_unregister": ([vp], i),
         "ekm_h2d": ([i, vp, vp, sz, vp], i), "ekm_d2h": ([i, vp, vp, sz, vp], i),
         "ekm_d2d": ([i, vp, vp, sz, vp], i), "ekm_memset": ([i, vp, i, sz, vp], i),
         "ekm_sync": ([i], i),
@@ -65,7 +63,7 @@ def _signatures():
         "ekm_event_record": ([i, vp, vp], i), "ekm_event_sync": ([i, vp], i),
         "ekm_stream_wait_event": ([i, vp, vp], i),
         "ekm_event_elapsed_ms": ([i, vp, vp, C.POINTER(C.c_float)], i),
-        "ekm_set_tuning": ([i, i], i), "ekm_set_tuning_param": ([C.c_char_p, i], i), "ekm_get_tuning": ([C.POINTER(i), C.POINTER(i)], i),
+        "ekm_set_tuning": ([i, i], i), "ekm_set_tuning_param": ([C.c_char_p, i], i), "ekm_prepare_tables": ([i], i), "ekm_get_tuning": ([C.POINTER(i), C.POINTER(i)], i),
         "ekm_synth_fill_f32": ([i, vp, vp, vp, vp, u64, sz, u64, u32, u64], i),
         "ekm_synth_fill_f64": ([i, vp, vp, vp, vp, u64, sz, u64, u32, u64], i),
         "ekm_synth_fill_given_p_f32": ([i, vp, vp, vp, vp, u64, sz, u64], i),

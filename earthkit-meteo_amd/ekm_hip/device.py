@@ -224,10 +224,6 @@ def _register_owner(owner):
 def _owners_snapshot():
     with _owners_lock:
         return list(_live_owners)
-_STAGGER_MIN_BYTES = 1 << 20   # only blocks of at least 1 MiB (fields) are staggered
-_STAGGER_STEP = 20 << 10       # 20 KiB: 5 x 4 KiB
-_STAGGER_SLOTS = 16
-_stagger_seq = itertools.count()
 
 
 def empty_cache():
@@ -264,16 +260,9 @@ class _Allocation:
     def __init__(self, nbytes, device, capacity=0):
         self.device, self.nbytes, self.stream = device, nbytes, current_stream()
         nbytes = max(nbytes, int(capacity))  # `capacity`: block size to reserve (the streamed path recycles equal blocks)
-        # Large blocks start at a staggered offset inside their allocation (a different multiple of 20 KiB for
-        # each of 16 consecutive allocations).  hipMalloc returns 2-MiB-aligned blocks, so without it the fields a
-        # kernel streams together all sit at the same offset inside their pages and -- depending on where the pages
-        # land physically -- pile onto the same HBM channels: measured on four buffer sets in one process
-        # (tools/placement_probe.py, profiles/r02_placement_probe.txt) the fused pipelines vary 3.46-3.88 ms (P3) and
-        # 5.49-5.73 ms (P5) unstaggered, 3.47-3.63 and 5.41-5.58 ms staggered by k x 20 KiB.
-        stagger = 0
-        if nbytes >= _STAGGER_MIN_BYTES:
-            stagger = (next(_stagger_seq) % _STAGGER_SLOTS) * _STAGGER_STEP
-            nbytes = nbytes + _STAGGER_SLOTS * _STAGGER_STEP
+        # (Round 2 started large blocks at staggered offsets inside their allocations; round 3 showed that the distance
+        # between the streams of a kernel is not what its speed depends on -- profiles/r03_placement_arena_skews.txt --
+        # so the blocks are plain again.)
         self.bucket = _BlockCache.bucket(nbytes)
         self.exported = False  # handed to a DLPack consumer, whose streams are unknown here
         self._lock = threading.Lock()
@@ -285,7 +274,7 @@ class _Allocation:
                 _cache.drain()
                 _ffi.check(_ffi.lib().ekm_malloc(device, self.bucket, C.byref(out)))
             ptr = out.value
-        self.base, self.ptr = ptr, ptr + stagger
+        self.base, self.ptr = ptr, ptr
         _cache.note(device, self.bucket)
         _register_owner(self)
 
@@ -469,17 +458,22 @@ class _PinnedPool:
 
     A device-to-host copy into pinned memory is a plain DMA at the link rate (57 GB/s on the GPU box), with no page
     faults and none of the pin / unpin work the runtime does around every copy into pageable memory.  hipHostMalloc is
-    slow (it pins page by page), so blocks are recycled: the NumPy array handed to the caller owns its block through a
-    finalizer, and when the caller drops the array (and every view of it) the block comes back here.  Cached blocks
-    are bounded by EKM_PINNED_CACHE_BYTES (default 8 GiB), beyond that they are freed; and once the callers hold
-    EKM_PINNED_LIVE_BYTES (default 32 GiB) of pinned results alive, further results are ordinary pageable arrays."""
+    slow (it pins page by page), so blocks are recycled: the NumPy array handed to the caller keeps its block alive
+    through a finalizer, and when the caller drops the array (and every view of it) the block comes back here.
+    Page-locked memory cannot be swapped and counts against container / memlock limits, so the pool is small by
+    default: once the callers hold EKM_PINNED_LIVE_BYTES (default 4 GiB) of pinned results alive, further results are
+    ordinary pageable arrays, and at most EKM_PINNED_CACHE_BYTES (default 1 GiB) of dropped blocks stay cached, the rest
+    is freed at once (`ekm_hip.empty_cache()` frees the cached ones too).  An array in pooled memory does not own its
+    data: `.base` is a ctypes buffer and `ndarray.resize` refuses."""
 
     def __init__(self):
         self.free = {}    # bucket -> [ptr, ...]
         self.cached = 0
-        self.limit = int(os.environ.get("EKM_PINNED_CACHE_BYTES", str(8 << 30)))
-        self.live_limit = int(os.environ.get("EKM_PINNED_LIVE_BYTES", str(32 << 30)))  # pinned bytes callers may hold at once
-        self.lock = threading.Lock()
+        self.limit = int(os.environ.get("EKM_PINNED_CACHE_BYTES", str(1 << 30)))
+        self.live_limit = int(os.environ.get("EKM_PINNED_LIVE_BYTES", str(4 << 30)))  # pinned bytes callers may hold at once
+        # re-entrant: give() runs from a weakref finalizer, which the cyclic garbage collector may fire at any allocation
+        # inside take() / give() / drain() of the very thread that holds the lock
+        self.lock = threading.RLock()
         self.handed_out = 0
 
     @staticmethod
@@ -490,18 +484,18 @@ class _PinnedPool:
     def take(self, nbytes):
         b = self.bucket(nbytes)
         with self.lock:
+            if self.handed_out + b > self.live_limit:
+                return None, b  # the caller keeps many results alive: further ones are ordinary pageable arrays
+            self.handed_out += b  # reserved under the lock, before the (slow) allocation: the limit cannot be overshot
             lst = self.free.get(b)
             if lst:
                 self.cached -= b
-                self.handed_out += b
                 return lst.pop(), b
-            if self.handed_out + b > self.live_limit:
-                return None, b  # the caller keeps many results alive: further ones are ordinary pageable arrays
         out = C.c_void_p()
         if _ffi.lib().ekm_host_alloc(b, C.byref(out)) < 0 or not out.value:
+            with self.lock:
+                self.handed_out -= b  # roll the reservation back
             return None, b
-        with self.lock:
-            self.handed_out += b
         return out.value, b
 
     def give(self, ptr, b):

@@ -61,8 +61,14 @@ with torch.cuda.stream(side):
     strided = ek.thermo.saturation_vapour_pressure(ut.t())          # not C-contiguous: the producer compacts it
     assert isinstance(strided, torch.Tensor) and tuple(strided.shape) == tuple(ut.t().shape)
     assert np.array_equal(strided.cpu().numpy(), ek.thermo.saturation_vapour_pressure(np.ascontiguousarray(t.T)), equal_nan=True)
-    host_t = ek.thermo.potential_temperature(torch.from_numpy(t), torch.from_numpy(p))   # CPU tensors: NumPy semantics
-    assert isinstance(host_t, np.ndarray)
+    # CPU tensors: computed through the NumPy path, and -- as the reference does for every backend -- handed back as torch
+    host_t = ek.thermo.potential_temperature(torch.from_numpy(t), torch.from_numpy(p))
+    assert isinstance(host_t, torch.Tensor) and host_t.device.type == "cpu" and host_t.dtype == torch.float32
+    assert np.array_equal(host_t.numpy(), ek.thermo.potential_temperature(t, p), equal_nan=True)
+    host_s = ek.thermo.potential_temperature(torch.tensor(264.12, dtype=torch.float64), 85000.0)   # 0-d tensor: 0-d tensor
+    assert isinstance(host_s, torch.Tensor) and host_s.ndim == 0 and abs(float(host_s) - 276.672291) < 1e-5
+    host_mix = ek.thermo.potential_temperature(torch.from_numpy(t), p)                             # NumPy among them: NumPy out
+    assert isinstance(host_mix, np.ndarray)
     # the vertical functions take foreign arrays the same way (ekm_hip.vertical._foreign_aware)
     A_, B_ = ek.vertical.hybrid_level_parameters(137)
     sp_t = torch.full((64, 32), 101325.0, device=dev) * (1.0 - 0.3 * torch.rand(64, 32, device=dev))
@@ -78,6 +84,51 @@ with torch.cuda.stream(side):
     assert isinstance(z, torch.Tensor) and np.array_equal(z.cpu().numpy(), z_host)
     del out, es_, td_, rh_, mixed, plain, strided, pf, z
 torch.cuda.synchronize()
+
+# the reference parametrises EVERY function over its array backends (tests/thermo/test_thermo.py:73 ...): every public
+# function x variant of the case table with torch-ROCm inputs against the DeviceArray path -- the same bits, torch out
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from _case_table import case_table  # noqa: E402
+
+rng = np.random.default_rng(11)
+npts = 1 << 14
+col = {"t": rng.uniform(215.0, 315.0, npts), "p": 10.0 ** rng.uniform(3.0, 5.02, npts)}
+col["tc"] = col["t"] - 273.16
+col["t2"] = col["t"] - rng.uniform(0.0, 15.0, npts)
+col["td"] = col["t"] - rng.uniform(0.0, 25.0, npts)
+col["q"] = 10.0 ** rng.uniform(-6.0, -1.8, npts)
+col["w"] = col["q"] / (1.0 - col["q"])
+col["p2"] = col["p"] * rng.uniform(0.5, 1.0, npts)
+col["e"] = col["p"] * col["q"] / 0.622
+col["es"] = 611.21 * np.exp(17.502 * (col["t"] - 273.16) / (col["t"] - 32.19))
+col["r"] = rng.uniform(1.0, 100.0, npts)
+col["th"] = col["t"] * (1e5 / col["p"]) ** 0.2857
+col["ept"] = col["th"] + rng.uniform(0.0, 40.0, npts)
+ncase = 0
+for tag, npdt, tdt in (("f32", np.float32, torch.float32), ("f64", np.float64, torch.float64)):
+    host = {k: v.astype(npdt) for k, v in col.items()}
+    tens = {k: torch.from_numpy(v).to(dev) for k, v in host.items()}
+    devs = {k: ek.to_device(v) for k, v in host.items()}
+    for func, names, kwargs in case_table():
+        fn = getattr(ek.thermo, func)
+        got = fn(*[tens[n] for n in names], **kwargs)
+        want_ = fn(*[devs[n] for n in names], **kwargs)
+        got = got if isinstance(got, tuple) else (got,)
+        want_ = want_ if isinstance(want_, tuple) else (want_,)
+        for g, w in zip(got, want_):
+            assert isinstance(g, torch.Tensor) and g.device == dev and g.dtype == tdt and tuple(g.shape) == (npts,), (func, kwargs, type(g))
+            assert np.array_equal(g.cpu().numpy(), w.to_host(), equal_nan=True), f"{func} {kwargs} {tag}: torch path differs from the DeviceArray path"
+        ncase += 1
+    # ... and with torch CPU tensors (the NumPy path underneath): torch CPU tensors out, the same bits again
+    for func, names, kwargs in case_table()[::7]:
+        fn = getattr(ek.thermo, func)
+        got = fn(*[torch.from_numpy(host[n]) for n in names], **kwargs)
+        want_ = fn(*[devs[n] for n in names], **kwargs)
+        for g, w in zip(got if isinstance(got, tuple) else (got,), want_ if isinstance(want_, tuple) else (want_,)):
+            assert isinstance(g, torch.Tensor) and g.device.type == "cpu" and g.dtype == tdt
+            assert np.array_equal(g.numpy(), w.to_host(), equal_nan=True), f"{func} {kwargs} {tag}: torch CPU path differs"
+    del tens, devs
+print(f"torch-ROCm inputs: {ncase} function x variant x dtype cases bit-equal to the DeviceArray path")
 
 # a second round on our own non-default stream: producer is handed that stream
 s1 = ek.stream_create()

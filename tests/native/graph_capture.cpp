@@ -80,5 +80,53 @@ int main() {
     }
   }
   printf("graph capture + 3 replays: identical to direct launches\n");
+
+  // ---- no entry point waits on the host: the FIRST use of a table-driven function (bolton35 bisection: its own table)
+  // on stream s3 while stream s is capturing in global mode.  A host synchronisation here would be illegal and would
+  // invalidate the capture; the table fill must go onto s3 with an event behind it instead.
+  hipStream_t s3;
+  CHK(hipStreamCreate(&s3));
+  hipGraph_t g2;
+  CHK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+  EKM(ekm_pipeline_svp_td_rh_f32(0, s, &ot, &oq, &op, o[0], o[1], o[2], n));
+  EKM(ekm_wet_bulb_temperature_from_specific_humidity_f32(0, s3, &ot, &oq, &op, EKM_EPT_BOLTON35, EKM_T_BISECT, o[3], n));
+  // ... and a second stream right behind it, before the fill can have been seen complete: it must wait on the device
+  hipStream_t s4;
+  CHK(hipStreamCreate(&s4));
+  EKM(ekm_wet_bulb_temperature_from_specific_humidity_f32(0, s4, &ot, &oq, &op, EKM_EPT_BOLTON35, EKM_T_BISECT, o[4], n));
+  hipError_t endrc = hipStreamEndCapture(s, &g2);
+  if (endrc != hipSuccess) {
+    printf("the capture on s was invalidated by a launch on another stream: %s\n", hipGetErrorString(endrc));
+    return 1;
+  }
+  CHK(hipStreamSynchronize(s3));
+  CHK(hipStreamSynchronize(s4));
+  EKM(ekm_wet_bulb_temperature_from_specific_humidity_f32(0, s3, &ot, &oq, &op, EKM_EPT_BOLTON35, EKM_T_BISECT, r[3], n));
+  CHK(hipStreamSynchronize(s3));
+  {
+    std::vector<float> a(n), b(n), c(n);
+    CHK(hipMemcpy(a.data(), o[3], n * 4, hipMemcpyDeviceToHost));
+    CHK(hipMemcpy(c.data(), o[4], n * 4, hipMemcpyDeviceToHost));
+    CHK(hipMemcpy(b.data(), r[3], n * 4, hipMemcpyDeviceToHost));
+    if (std::memcmp(a.data(), b.data(), n * 4) != 0 || std::memcmp(c.data(), b.data(), n * 4) != 0) {
+      printf("first use on a side stream during a capture: results differ from a later launch\n");
+      return 1;
+    }
+  }
+  printf("first use of a table op on side streams during a global capture: capture intact, results identical\n");
+
+  // ---- ekm_prepare_tables: after it a capture of a table-driven function holds the kernel alone (no fill node)
+  EKM(ekm_prepare_tables(0));
+  hipGraph_t g3;
+  CHK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+  EKM(ekm_wet_bulb_temperature_from_specific_humidity_f32(0, s, &ot, &oq, &op, EKM_EPT_BOLTON39, EKM_T_BISECT, o[4], n));
+  CHK(hipStreamEndCapture(s, &g3));
+  size_t nodes = 0;
+  CHK(hipGraphGetNodes(g3, nullptr, &nodes));
+  if (nodes != 1) {
+    printf("after ekm_prepare_tables a captured bisection launch has %zu nodes (expected 1)\n", nodes);
+    return 1;
+  }
+  printf("ekm_prepare_tables: captured bisection launch is one node\n");
   return 0;
 }

@@ -161,18 +161,27 @@ def test_foreign_device_arrays_are_adopted_implicitly(monkeypatch):
     wrapped = []
     monkeypatch.setattr(dlpack, "from_dlpack", lambda x: wrapped.append(x.tag) or DeviceArray(None, 0, (2,), np.float32, 0))
     args, mod = _engine._adopt_foreign((Foreign("t"), Foreign("q"), 85000.0))
-    assert wrapped == ["t", "q"] and mod == "fakelib" and all(isinstance(a, DeviceArray) for a in args[:2]) and args[2] == 85000.0
+    assert wrapped == ["t", "q"] and mod == ("fakelib", "device") and all(isinstance(a, DeviceArray) for a in args[:2]) and args[2] == 85000.0
     _, mod = _engine._adopt_foreign((Foreign("t"), np.ones(2)))          # a NumPy array among them: our own types out
     assert mod is None
     _, mod = _engine._adopt_foreign((Foreign("t"), DeviceArray(None, 0, (2,), np.float32, 0)))
     assert mod is None
-    cpu = Foreign("c", dev_type=1)                                        # a CPU tensor is left to np.asarray
-    args, mod = _engine._adopt_foreign((cpu,))
-    assert args[0] is cpu and mod is None
+    # a HOST array of a foreign library (kDLCPU): viewed as NumPy (this one refuses the DLPack export: its own conversion),
+    # and -- the reference returns the caller's type for every backend, CPU tensors included -- handed back through the library
+    cpu = Foreign("c", dev_type=1)
+    args, mod = _engine._adopt_foreign((cpu, 2.0))
+    assert isinstance(args[0], np.ndarray) and args[0].tolist() == [1.0, 2.0] and mod == ("fakelib", "host")
+    _, mod = _engine._adopt_foreign((cpu, Foreign("t")))                  # host and device arrays of one library mixed
+    assert mod is None
     # handing back: through the library the CALLER imported, never imported here
     fake = types.ModuleType("fakelib")
     fake.from_dlpack = lambda r: ("fakelib tensor", r)
+    fake.asarray = lambda r: ("fakelib scalar", r)
     monkeypatch.setitem(sys.modules, "fakelib", fake)
     r = DeviceArray(None, 0, (2,), np.float32, 0)
-    assert _engine._hand_back((r,), "fakelib") == (("fakelib tensor", r),)
-    assert _engine._hand_back((r,), "not_imported_lib") == (r,)
+    assert _engine._hand_back((r,), ("fakelib", "device")) == (("fakelib tensor", r),)
+    assert _engine._hand_back((r,), ("not_imported_lib", "device")) == (r,)
+    h = np.arange(3.0)
+    back = _engine._hand_back((h, np.float64(2.5)), ("fakelib", "host"))
+    assert back[0][0] == "fakelib tensor" and back[0][1] is h and back[1] == ("fakelib scalar", np.float64(2.5))
+    assert _engine._hand_back((h,), ("not_imported_lib", "host")) == (h,)

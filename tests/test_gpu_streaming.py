@@ -38,23 +38,17 @@ def test_large_multi_output_numpy_call_is_bit_equal_to_the_device_path(ek):
             assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), f"rep {rep} output {k} differs"
 
 
-@pytest.mark.parametrize("route", ["staged", "pinned"])
-def test_alternative_transfer_routes_are_bit_equal(ek, monkeypatch, route):
-    """The streamed path can move its slices through the library's pinned staging ring (ekm_copy_staged, EKM_STAGED=1)
-    or with the caller's memory pinned in place slice by slice (hipHostRegister, EKM_PIN_HOST=1) instead of plain
-    pageable copies (the default: it is the fastest of the three on this host, profiles/r03_host_path_rate.txt).  Both
-    must give the bits of the device path, leave nothing pinned, and handle slices that are not page multiples."""
+def test_converted_operands_share_the_slice_pipeline(ek):
+    """float64 inputs with a float32 override are converted copies: they travel with the other operands of a slice, rows
+    of 8 MiB + 4112 B put the slice boundaries off the page grid, and the results are the bits of the device path."""
     from ekm_hip import _engine
 
-    t, q, p = _fields(16, (1 << 21) + 1028)  # rows of 8 MiB + 4112 B: slice boundaries off the page grid
+    t, q, p = _fields(16, (1 << 21) + 1028)
     want = _device_path(ek, "pipeline_svp_td_rh", (t, q, p))
-    monkeypatch.setattr(_engine, "_STAGED", route == "staged")
-    monkeypatch.setattr(_engine, "_PINNED", route == "pinned")
     for rep in range(2):
         got = ek.thermo.pipeline_svp_td_rh(t, q, p)
         for k, (g, w) in enumerate(zip(got, want)):
-            assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), f"{route} rep {rep} output {k} differs"
-    # float64 inputs with a float32 override are converted copies: they take the plain route inside the same pipeline
+            assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), f"rep {rep} output {k} differs"
     got64 = _engine._run_streamed("potential_temperature", (t.astype(np.float64), p), (), None, np.float32, [ek.current_device()])[0]
     assert np.array_equal(got64, _device_path(ek, "potential_temperature", (t, p))[0])
 

@@ -179,18 +179,7 @@ EKM_API int ekm_malloc(int dev, size_t bytes, void** out);
 EKM_API int ekm_free(int dev, void* ptr);
 EKM_API int ekm_host_alloc(size_t bytes, void** out);  /* pinned host memory for fast transfers */
 EKM_API int ekm_host_free(void* ptr);
-EKM_API int ekm_host_prefault(void* ptr, size_t bytes, int nthreads); /* fault in every page of a host buffer; never changes its contents */
-EKM_API int ekm_host_memcpy(void* dst, const void* src, size_t bytes, int nthreads); /* host-to-host copy on `nthreads` threads (staging through pinned buffers) */
-/* Move `nseg` host<->device segments through a ring of pinned staging buffers with `nthreads` copy threads, as ONE
- * pipelined job (the NumPy-in / NumPy-out path: pageable caller memory on one side).  to_device = 1: dst[] device,
- * src[] host; returns once every chunk has been copied out of the caller's memory and its DMA is enqueued on
- * `stream` (later work on that stream sees the data; the caller's memory may be reused at once).  to_device = 0:
- * dst[] host, src[] device; the DMAs are enqueued on `stream` (after the work already there) and the call returns
- * when all data is in the caller's memory.  An upload and a download job may run at the same time (full duplex). */
-EKM_API int ekm_copy_staged(int dev, int to_device, int nseg, void* const* dst, const void* const* src,
-                            const size_t* bytes, void* stream, int nthreads);
-EKM_API int ekm_host_register(void* ptr, size_t bytes);   /* pin caller-owned host memory in place (hipHostRegister) */
-EKM_API int ekm_host_unregister(void* ptr);
+EKM_API int ekm_host_prefault(void* ptr, size_t bytes, int nthreads); /* touch the pages of a fresh host buffer on `nthreads` threads */
 EKM_API int ekm_h2d(int dev, void* dst, const void* src, size_t bytes, void* stream);
 EKM_API int ekm_d2h(int dev, void* dst, const void* src, size_t bytes, void* stream);
 EKM_API int ekm_d2d(int dev, void* dst, const void* src, size_t bytes, void* stream);
@@ -213,13 +202,19 @@ EKM_API int ekm_set_tuning(int tiles_per_block, int unroll);
 EKM_API int ekm_get_tuning(int* tiles_per_block, int* unroll);
 /* secondary parameters by name (defaults from the environment, in brackets):
  *   "hybrid_band_kb" [EKM_HYBRID_BAND_KB, 8192]  EKM_HYBRID_FULL: KiB of surface pressure per L2-resident band;
- *   "lev_per_wg"     [EKM_LEV_PER_WG, 0]         EKM_HYBRID_FULL: consecutive levels one workgroup walks (0 = by stream count);
+ *   "lev_per_wg"     [EKM_LEV_PER_WG, 0]         EKM_HYBRID_FULL, one-in one-out functions only (theta ...): consecutive levels one workgroup walks (0 = 4); no effect on functions with more streams;
  *   "table_tiles"    [EKM_TABLE_TILES, 8]        most tiles per workgroup for ops that keep an LDS table (bisection);
  *   "geo_chunk_levels" [EKM_GEO_CHUNK_LEVELS, all] levels per launch of the geopotential column scan;
  *   "f64_plain"        [EKM_F64_PLAIN, 0]          1: the fp64 map kernels redo EVERY lane with the plain-double primitives
  *                      (IEEE special operands fixed up as libm does) instead of only the lanes whose fast first pass
  *                      produced a non-finite output; same results, for tests and A/B timing. */
 EKM_API int ekm_set_tuning_param(const char* name, int value);
+/* The table-driven functions (wet-bulb / moist-adiabat inversion by bisection) read a lookup table that is computed on
+ * the device at their first launch there -- asynchronously: no entry point of this library waits on the host.  A
+ * launch captured into a HIP graph before the table exists records the fill into that graph.  ekm_prepare_tables(dev)
+ * computes every table on `dev` now and WAITS for it (the one synchronising call; not while capturing), so that later
+ * launches and captures find them ready. */
+EKM_API int ekm_prepare_tables(int dev);
 
 /* ---- synthetic benchmark input, generated on the device (SURVEY.md 8d) ----
  * Fills t, q (and p unless NULL) for points [first, first+n) of a level-major

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the NumPy-in / NumPy-out path (reported beside, never as, the HBM-resident
 `value`): P3, theta and P5 on an 8-level and a 32-level slab of the benchmark field (1800 x 3600 fp32 points per
-level = 26 MB per level and array), pageable caller memory, best of 5 calls, by three routes: plain pageable
-hipMemcpyAsync (the round-2 path, EKM_PIN_HOST=0), staged through the library's pinned ring with threaded host copies
-(EKM_STAGED=1), and with the caller's memory pinned in place slice by slice ahead of the transfers (the default)."""
+level = 26 MB per level and array), best of 5 calls: results in ordinary pageable arrays (EKM_PINNED_RESULTS=0), results
+in pooled pinned memory (the default), and the caller's inputs in pinned memory too (ekm_hip.pinned_empty).  (Round 3
+also timed three routes that were removed in round 4: profiles/r03_host_path_rate.txt.)"""
 import os
 import sys
 import time
@@ -19,11 +19,7 @@ from oracle import synthetic  # noqa: E402
 for nlev in (8, 32):
     t, q, p, _ = synthetic.make_fields(nlev, 1800 * 3600, dtype=np.float32, seed=3)
     n = t.size
-    for mode in ("pageable", "pooled", "pooled+pinin", "pooled+in", "staged", "pinned", "mixed"):
-        # mixed: inputs pinned in place, results through the ring; pooled: results in pooled pinned memory (the default);
-        # pooled+in: the caller's inputs in pinned memory too (ekm_hip.pinned_empty)
-        # pooled+pinin: results pooled AND the caller's (pageable) inputs pinned in place slice by slice ahead of the uploads
-        _engine._STAGED, _engine._PINNED = mode in ("staged", "mixed"), mode in ("pinned", "mixed", "pooled+pinin")
+    for mode in ("pageable", "pooled", "pooled+in"):
         _engine._PINNED_OUT = mode.startswith("pooled")
         args3 = (t, q, p)
         if mode == "pooled+in":
