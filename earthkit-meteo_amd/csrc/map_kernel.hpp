@@ -30,10 +30,7 @@
 
 namespace ekm {
 
-#ifndef EKM_THREADS
-#define EKM_THREADS 256
-#endif
-constexpr int kThreads = EKM_THREADS;
+constexpr int kThreads = EKM_THREADS_DEFAULT;  // threads per workgroup unless the op says otherwise (ops.hpp::OpThreads)
 #ifndef EKM_WAVES_PER_EU
 #define EKM_WAVES_PER_EU 1
 #endif
@@ -73,7 +70,8 @@ struct MapArgs {
   unsigned long long step_q[NIN];  // (elements per tile) / inner   resp. unused
   unsigned long long step_r[NIN];  // (elements per tile) % inner   resp. % len
   int vec_ok;                    // all field pointers 16-B aligned
-  int f64_plain;                 // fp64: redo every lane in plain double (tuning parameter f64_plain; tests / A-B only)
+  int switches;                  // test / A-B switches: bit 0 fp64: redo every lane in plain double (tuning parameter f64_plain);
+                                 // bit 1 fp32 IFS bisection: the exact residual at every step (bisect_exact)
   const T* aux0;                 // EKM_HYBRID_FULL (last operand): A half-level table
   const T* aux1;                 //                                 B half-level table
 };
@@ -134,8 +132,8 @@ __device__ __forceinline__ void op_apply(const T* __restrict__ x, T* __restrict_
 // lets the compiler interleave the V independent points (4-8 % on the wet-bulb kernels).
 template <class Op, class T, int V>
 __device__ __forceinline__ void apply_points(const T (&x)[V][Op::NIN], T (&y)[V][Op::NOUT], T rp,
-                                             const T* __restrict__ tab, int f64_plain) {
-  (void)f64_plain;
+                                             const T* __restrict__ tab, int switches) {
+  (void)switches;
   if constexpr (OpUsesTie<Op>::value && sizeof(T) == 4 && OpTable<Op>::elems == 0) {
     TieFlag flag;
 #pragma unroll
@@ -147,6 +145,9 @@ __device__ __forceinline__ void apply_points(const T (&x)[V][Op::NIN], T (&y)[V]
         for (int j = 0; j < V; ++j) Op::template apply_tie<T>(x[j], y[j], rp, exact);
       }
     }
+  } else if constexpr (sizeof(T) == 4 && OpTable<Op>::elems > 0 && OpTable<Op>::vectorized) {
+    // the IFS bisection walks its search tree step by step for all V points together (one wave-uniform branch per step)
+    OpTable<Op>::template apply_v<T, V>(x, y, rp, tab, (switches & 2) != 0);
   } else if constexpr (sizeof(T) == 8 && EKM_F64_TWO_PASS) {
     // fp64: first pass in fdouble (thermo_math.hpp: primitives without special-operand fix-ups, which poison to NaN
     // where a fix-up would have acted), then -- wave-uniform test, practically never taken on atmospheric data -- the
@@ -166,7 +167,7 @@ __device__ __forceinline__ void apply_points(const T (&x)[V][Op::NIN], T (&y)[V]
       }
     }
 #ifndef EKM_CENSUS_FAST_ONLY  // (ISA census aid: the first pass alone)
-    const bool redo = fin == 0u || f64_plain != 0;  // f64_plain (tuning parameter, wave-uniform): every lane takes the plain pass
+    const bool redo = fin == 0u || (switches & 1) != 0;  // f64_plain (tuning parameter, wave-uniform): every lane takes the plain pass
     if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
       if (redo) {
         // one copy of the plain-double body, the point picked by selects: indexing x[j] / y[j] with a loop counter
@@ -209,20 +210,20 @@ static __global__ __launch_bounds__(kThreads) void fill_op_table() {
   Tab::template fill<T>(g_op_table<Tab, T>, (int)(blockIdx.x * kThreads + threadIdx.x), (int)(gridDim.x * kThreads));
 }
 
-template <class Tab, class T>
+template <class Tab, class T, int NT>
 __device__ __forceinline__ void load_op_table(T* __restrict__ lds) {
   typedef typename VecOf<T>::type Vec;
   constexpr int NV = Tab::template count<T>() / VecOf<T>::N;  // the counts are multiples of the vector width
   const Vec* __restrict__ src = reinterpret_cast<const Vec*>(g_op_table<Tab, T>);
   Vec* __restrict__ dst = reinterpret_cast<Vec*>(lds);
 #pragma unroll 4
-  for (int i = threadIdx.x; i < NV; i += kThreads) dst[i] = src[i];
+  for (int i = threadIdx.x; i < NV; i += NT) dst[i] = src[i];
 }
 
 #define EKM_OP_TABLE(Op, T, name)                                              \
   __shared__ __attribute__((aligned(16))) T name[OpTable<Op>::elems > 0 ? OpTable<Op>::template count<T>() : 4]; \
   if constexpr (OpTable<Op>::elems > 0) {                                      \
-    load_op_table<typename OpTable<Op>::table_type, T>(name);                  \
+    load_op_table<typename OpTable<Op>::table_type, T, OpThreads<Op, T>::value>(name); \
     __syncthreads();                                                           \
   }
 
@@ -232,19 +233,19 @@ __device__ __forceinline__ void load_op_table(T* __restrict__ lds) {
 // moment the chip reads and writes one moving window of each stream.  Measured on
 // MI355X this beats a persistent grid-stride loop by 10-25 % (profiles/).
 template <class Op, class T, int UNROLL>
-__global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_fields(const MapArgs<T, Op::NIN, Op::NOUT> a, unsigned tiles) {
-  constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N;
+__global__ __launch_bounds__((OpThreads<Op, T>::value), (OpThreads<Op, T>::field_waves)) void map_fields(const MapArgs<T, Op::NIN, Op::NOUT> a, unsigned tiles) {
+  constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N, NT = OpThreads<Op, T>::value;
   typedef typename VecOf<T>::type Vec;
   EKM_OP_TABLE(Op, T, op_tab)
   const unsigned long long nvec = a.n / V;
-  const unsigned long long base = (unsigned long long)blockIdx.x * tiles * kThreads + threadIdx.x;
+  const unsigned long long base = (unsigned long long)blockIdx.x * tiles * NT + threadIdx.x;
 
   for (unsigned k = 0; k < tiles; k += UNROLL) {
-    const unsigned long long v0 = base + (unsigned long long)k * kThreads;
+    const unsigned long long v0 = base + (unsigned long long)k * NT;
     Vec xin[UNROLL][NIN];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const unsigned long long v = v0 + u * kThreads;
+      const unsigned long long v = v0 + u * NT;
       if (v < nvec) {
 #pragma unroll
         for (int i = 0; i < NIN; ++i) xin[u][i] = ld_stream<T>(a.in[i] + v * V);
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_fields(const M
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const unsigned long long v = v0 + u * kThreads;
+      const unsigned long long v = v0 + u * NT;
       if (v < nvec) {
         Vec yout[NOUT];
         T x[V][NIN], y[V][NOUT];
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_fields(const M
 #pragma unroll
           for (int i = 0; i < NIN; ++i) x[j][i] = xin[u][i][j];
         }
-        apply_points<Op, T, V>(x, y, a.rp, op_tab, a.f64_plain);
+        apply_points<Op, T, V>(x, y, a.rp, op_tab, a.switches);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
 #pragma unroll
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_fields(const M
     }
   }
   // ragged tail: n % V single elements, done by the first lanes of workgroup 0
-  const unsigned long long e = nvec * V + (unsigned long long)blockIdx.x * kThreads + threadIdx.x;
+  const unsigned long long e = nvec * V + (unsigned long long)blockIdx.x * NT + threadIdx.x;
 #ifdef EKM_CENSUS_FAST_ONLY
   if (false) {
 #else
@@ -292,8 +293,8 @@ __global__ __launch_bounds__(kThreads, EKM_WAVES_PER_EU) void map_fields(const M
 extern __shared__ __align__(16) unsigned char ekm_lds_raw[];
 
 template <class Op, class T>
-__global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, Op::NOUT> a, unsigned tiles) {
-  constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N;
+__global__ __launch_bounds__((OpThreads<Op, T>::value)) void map_bcast(const MapArgs<T, Op::NIN, Op::NOUT> a, unsigned tiles) {
+  constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N, NT = OpThreads<Op, T>::value;
   typedef typename VecOf<T>::type Vec;
   T* lds = reinterpret_cast<T*>(ekm_lds_raw);
   EKM_OP_TABLE(Op, T, op_tab)
@@ -305,12 +306,12 @@ __global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, 
     sval[i] = T(0);
     if (a.mode[i] == EKM_SCALAR) sval[i] = a.in[i][0];
     if (a.mode[i] >= EKM_LEVEL_MAJOR)
-      for (unsigned s = threadIdx.x; s < a.len[i]; s += kThreads) lds[a.lds_off[i] + s] = a.in[i][s];
+      for (unsigned s = threadIdx.x; s < a.len[i]; s += NT) lds[a.lds_off[i] + s] = a.in[i][s];
   }
   __syncthreads();
 
   const unsigned long long nchunk = (a.n + V - 1) / V;  // last chunk may be partial
-  const unsigned long long cblock = (unsigned long long)blockIdx.x * tiles * kThreads;  // wave-uniform
+  const unsigned long long cblock = (unsigned long long)blockIdx.x * tiles * NT;  // wave-uniform
 
   // Position of this lane's first chunk in every level operand: one division per workgroup
   // on the scalar unit (cblock is uniform), then carried forward by one tile per trip.
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, 
   }
 
   for (unsigned k = 0; k < tiles; ++k) {
-    const unsigned long long c = cblock + (unsigned long long)k * kThreads + threadIdx.x;
+    const unsigned long long c = cblock + (unsigned long long)k * NT + threadIdx.x;
     if (c < nchunk) {
       const unsigned long long e0 = c * V;
       const bool full = (e0 + V <= a.n);
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, 
 #pragma unroll
         for (int i = 0; i < NIN; ++i) x[j][i] = xin[i][j];
       }
-      apply_points<Op, T, V>(x, y, a.rp, op_tab, a.f64_plain);
+      apply_points<Op, T, V>(x, y, a.rp, op_tab, a.switches);
 #pragma unroll
       for (int j = 0; j < V; ++j) {
 #pragma unroll
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(kThreads) void map_bcast(const MapArgs<T, Op::NIN, 
         }
       }
     }
-    // advance the running positions by one tile (kThreads * V elements)
+    // advance the running positions by one tile (NT * V elements)
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
       if (a.mode[i] == EKM_LEVEL_MAJOR) {
@@ -449,7 +450,7 @@ struct LevArgs {
   unsigned last;         // highest valid index of the level vector / full-level index
   unsigned lev_per_wg;   // consecutive levels one workgroup walks (WALK instantiation only; else 1)
   unsigned tiles;        // consecutive horizontal tiles per workgroup
-  int f64_plain;         // fp64: redo every lane in plain double (tuning parameter f64_plain; tests / A-B only)
+  int switches;          // test / A-B switches, as in MapArgs
   T rp;
 };
 
@@ -462,8 +463,8 @@ struct LevArgs {
 // WALK (PM_HYBRID only): the workgroup walks `lev_per_wg` > 1 consecutive levels of its tile with sp and the shared
 // half-level pressure in registers.
 template <class Op, class T, int PMODE, bool ALIGNED, bool WALK = false>
-__global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? OpWaves<Op>::value : EKM_WAVES_PER_EU)) void map_levels(const LevArgs<T, Op::NIN, Op::NOUT> a) {
-  constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N, PI = Op::NIN - 1;
+__global__ __launch_bounds__((OpThreads<Op, T>::value), (OpThreads<Op, T>::tree ? OpThreads<Op, T>::field_waves : sizeof(T) == 4 ? OpWaves<Op>::value : EKM_WAVES_PER_EU)) void map_levels(const LevArgs<T, Op::NIN, Op::NOUT> a) {
+  constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N, PI = Op::NIN - 1, NT = OpThreads<Op, T>::value;
   typedef typename VecOf<T>::type Vec;
   EKM_OP_TABLE(Op, T, op_tab)
   const unsigned lpw = WALK ? a.lev_per_wg : 1u;
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? OpWaves<Op>::value : EK
 
   for (unsigned i = 0; i < a.tiles; ++i) {
     const unsigned long long tile = (unsigned long long)blockIdx.z * gridDim.x + blockIdx.x;
-    const unsigned long long col64 = (tile * a.tiles + i) * (kThreads * V) + threadIdx.x * V;
+    const unsigned long long col64 = (tile * a.tiles + i) * (NT * V) + threadIdx.x * V;
     if (col64 >= a.inner) continue;
     const unsigned col = (unsigned)col64;
 
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(kThreads, (sizeof(T) == 4 ? OpWaves<Op>::value : EK
             for (int f = 0; f < PI; ++f) x[j][f] = xin[f][j];
             x[j][PI] = pressure(j);
           }
-          apply_points<Op, T, V>(x, y, a.rp, op_tab, a.f64_plain);
+          apply_points<Op, T, V>(x, y, a.rp, op_tab, a.switches);
 #pragma unroll
           for (int j = 0; j < V; ++j) {
 #pragma unroll
@@ -598,7 +599,8 @@ int tuning_unroll();
 int tuning_user_set();      // ekm_set_tuning has been called: the launch-shape heuristics of launch_map stand back
 int tuning_lev_per_wg();    // EKM_HYBRID_FULL: consecutive levels one workgroup walks (EKM_LEV_PER_WG, default 0 = by stream count)
 int tuning_hybrid_band_bytes();  // EKM_HYBRID_FULL: bytes of surface pressure per band (EKM_HYBRID_BAND_KB, default 8192 KiB)
-int tuning_table_tiles();   // most tiles per workgroup for ops that keep an LDS table (EKM_TABLE_TILES, default 8)
+int tuning_table_tiles();   // most tiles per workgroup for ops that keep an LDS table (EKM_TABLE_TILES, default 0 = by op)
+int tuning_bisect_exact();   // fp32 IFS bisection: 1 = the reference's residual at every step of the tree walk (EKM_BISECT_EXACT, default 0)
 int tuning_f64_plain();      // fp64 map kernels: 1 = every lane redone in plain double (EKM_F64_PLAIN, default 0)
 int tuning_geo_chunk_levels();  // levels per launch of the geopotential column scan (EKM_GEO_CHUNK_LEVELS, default: all in one launch)
 
@@ -608,8 +610,8 @@ constexpr unsigned kMaxLdsBytes = 64 * 1024;
 // stays free of synchronisation (it may run while another stream or thread of the process is capturing):
 //  * first use on a device, outside stream capture: the fill kernel goes onto the caller's stream, an event is recorded
 //    behind it, and the call returns; the caller's launch is ordered behind the fill by the stream itself;
-//  * later launches on OTHER streams wait for that event on the device (hipStreamWaitEvent) until a non-blocking
-//    hipEventQuery has seen it complete, from when on the table is marked ready and launches cost one atomic load;
+//  * later launches on OTHER streams wait for that event on the device (hipStreamWaitEvent) until a host function
+//    queued behind the fill has marked the table ready, from when on launches cost one atomic load;
 //  * under stream capture with the table not ready, the fill is recorded into the graph in front of the kernel that
 //    needs it (the graph is then self-contained); nothing global is marked, because the captured work has not run.
 //    ekm_prepare_tables(dev), called once outside capture, avoids that extra node.
@@ -679,18 +681,15 @@ static int ensure_op_table(int dev, hipStream_t s, bool wait) {
     if (err != hipSuccess) return set_error(EKM_ERR_HIP, "table fill event record: %s", hipGetErrorString(err));
     st.fill_stream = s;
     st.recorded = true;
-  } else {
-    err = hipEventQuery(st.filled);
-    if (err == hipSuccess) {
-      st.ready.store(1, std::memory_order_release);
-      return EKM_OK;
-    }
-    (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure
-    if (err != hipErrorNotReady) return set_error(EKM_ERR_HIP, "table fill event query: %s", hipGetErrorString(err));
-    if (s != st.fill_stream) {
-      err = hipStreamWaitEvent(s, st.filled, 0);  // device-side: this stream's kernel runs after the fill
-      if (err != hipSuccess) return set_error(EKM_ERR_HIP, "table fill wait: %s", hipGetErrorString(err));
-    }
+    // "ready" is set by a host function queued behind the fill -- not by polling the event: hipEventQuery is refused
+    // (and may invalidate the capture) while another stream of the calling thread captures in global mode.  If the
+    // host function cannot be queued the table simply never counts as ready and every launch keeps the device-side wait.
+    if (hipLaunchHostFunc(s, [](void* flag) { static_cast<std::atomic<int>*>(flag)->store(1, std::memory_order_release); },
+                          &st.ready) != hipSuccess)
+      (void)hipGetLastError();
+  } else if (s != st.fill_stream) {
+    err = hipStreamWaitEvent(s, st.filled, 0);  // device-side: this stream's kernel runs after the fill
+    if (err != hipSuccess) return set_error(EKM_ERR_HIP, "table fill wait: %s", hipGetErrorString(err));
   }
   if (wait) {  // ekm_prepare_tables only: an explicit, documented host wait
     err = hipEventSynchronize(st.filled);
@@ -702,7 +701,7 @@ static int ensure_op_table(int dev, hipStream_t s, bool wait) {
 
 template <class Op, class T>
 int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const* outs, size_t n, double rp) {
-  constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N;
+  constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N, NT = OpThreads<Op, T>::value;
   if (n == 0) return EKM_OK;
   int rc = use_device(dev);
   if (rc != EKM_OK) return rc;
@@ -714,7 +713,7 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
   a.aux0 = a.aux1 = nullptr;
   a.n = n;
   a.rp = T(rp);
-  a.f64_plain = tuning_f64_plain();
+  a.switches = tuning_f64_plain() | (tuning_bisect_exact() << 1);
   bool bc = false, aligned = true;
   unsigned lds_elems = 0;
   for (int i = 0; i < NIN; ++i) {
@@ -788,28 +787,34 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
                      (size_t)lds_elems * sizeof(T), (size_t)kMaxLdsBytes - kTableBytes, kTableBytes);
 
   const unsigned long long nchunk = (n + V - 1) / V;
-  const unsigned long long ntile = (nchunk + kThreads - 1) / kThreads;
+  const unsigned long long ntile = (nchunk + NT - 1) / NT;
   unsigned tiles = (unsigned)tuning_tiles_per_block();
   // an op that builds an LDS table per workgroup amortises it over more tiles (bisection: 4096 es values)
   // an op with an LDS table copies 32 KiB per workgroup from the device-resident table: a few tiles amortise that
-  if (OpTable<Op>::elems > 0 && tiles < (unsigned)tuning_table_tiles()) {
+  // (0 = by op: the 512-thread tree walk of the IFS bisection copies 48 KiB per workgroup and takes 16 tiles -- 8 on hybrid
+  // levels, whose bands want the workgroups short --, the 32-KiB tables 8; profiles/r04_bisect_tree_walk.txt)
+  unsigned table_tiles = (unsigned)tuning_table_tiles();
+  if (table_tiles == 0) table_tiles = OpThreads<Op, T>::tree && a.mode[NIN - 1] != EKM_HYBRID_FULL ? 16u : 8u;
+  if (OpTable<Op>::elems > 0 && tiles < table_tiles) {
     const int cus = device_cus(dev);
     unsigned long long most = ntile / (4ull * (unsigned long long)(cus > 0 ? cus : 256));  // >= 4 workgroups per CU
     if (most < 1) most = 1;
-    tiles = (unsigned)(most < (unsigned long long)tuning_table_tiles() ? most : (unsigned long long)tuning_table_tiles());
+    tiles = (unsigned)(most < (unsigned long long)table_tiles ? most : (unsigned long long)table_tiles);
   }
   int unroll = tuning_unroll();
   // Launch-shape heuristics, only while the caller has not set the tuning explicitly (ekm_set_tuning):
   //  * the VALU-bound fp32 Newton kernels (one output, regime tie inside) hide their loads better with the next tile's
   //    loads issued ahead: two tiles per workgroup, both in flight (3.45 -> 3.41 ms; the HBM-bound kernels prefer
   //    one-shot tiles);
-  //  * the fp64 kernels are VALU-bound with a long per-workgroup prologue (13 coefficient pairs through the scalar
-  //    cache): four tiles per workgroup (P5 14.47 -> 14.10 ms, wet-bulb 10.11 -> 9.93; profiles/r04_sweep_f64_tiles.txt).
+  //  * the fp64 Newton kernels (the same ops; VALU-bound, with a per-workgroup prologue of 13 coefficient pairs through
+  //    the scalar cache): four tiles per workgroup (P5 14.47 -> 14.10 ms, wet-bulb 10.11 -> 9.93;
+  //    profiles/r04_sweep_f64_tiles.txt).  The HBM-bound fp64 kernels keep one-shot tiles: with four they lose 6-14 %
+  //    (theta 3.35 -> 3.83 ms, P3 7.27 -> 7.72; profiles/r04_ab_vs_r03.txt).
   if (!tuning_user_set() && !bc && aligned && tiles == 1 && unroll == 1 && ntile >= 4096) {
     if (OpUsesTie<Op>::value && NOUT == 1 && sizeof(T) == 4) {
       tiles = 2;
       unroll = 2;
-    } else if (sizeof(T) == 8 && OpTable<Op>::elems == 0) {
+    } else if (sizeof(T) == 8 && OpUsesTie<Op>::value) {
       tiles = 4;
     }
   }
@@ -833,7 +838,7 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
       la.B = a.aux1;
       la.n = n;
       la.rp = a.rp;
-      la.f64_plain = a.f64_plain;
+      la.switches = a.switches;
       unsigned long long inner = a.inner[NIN - 1];
       la.last = pm == EKM_SCALAR ? 0u : a.len[NIN - 1] - 1u;
       if (pm == EKM_SCALAR) inner = n < (1ull << 30) ? n : (1ull << 30);  // one "level" of any convenient length
@@ -848,7 +853,7 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
       if (pm == EKM_HYBRID_FULL && kWalk) lpw = tuning_lev_per_wg() > 0 ? (unsigned)tuning_lev_per_wg() : 4u;
       // shapes this kernel is not meant for go to map_bcast: rows longer than 32-bit columns, more level
       // groups than gridDim.y allows, or rows much shorter than a workgroup (a vector along a short axis)
-      const bool fits = inner < (1ull << 31) && nlev <= 65535ull && (inner >= (unsigned long long)kThreads || pm == EKM_HYBRID_FULL);
+      const bool fits = inner < (1ull << 31) && nlev <= 65535ull && (inner >= (unsigned long long)NT || pm == EKM_HYBRID_FULL);
       if (!fits && pm == EKM_HYBRID_FULL)
         return set_error(EKM_ERR_ARG, "EKM_HYBRID_FULL: inner = %llu, len = %u is outside the supported range", inner,
                          a.len[NIN - 1]);
@@ -856,7 +861,7 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
       if (levels) {
         la.inner = (unsigned)inner;
         la.tiles = OpTable<Op>::elems > 0 ? tiles : 1u;
-        const unsigned long long per_wg = (unsigned long long)kThreads * V * la.tiles;
+        const unsigned long long per_wg = (unsigned long long)NT * V * la.tiles;
         const unsigned long long ntx = (inner + per_wg - 1) / per_wg;  // workgroups along one level
         // hybrid: bands of EKM_HYBRID_BAND_KB of surface pressure (L2-resident between levels); else one band
         unsigned long long band = ntx;
@@ -888,7 +893,7 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
           q.lev_per_wg = walk < q.nlev ? walk : q.nlev;
           const unsigned gy = (q.nlev + q.lev_per_wg - 1) / q.lev_per_wg;
           const dim3 g((unsigned)band, gy, (unsigned)((ntx + band - 1) / band));
-#define EKM_LEV_LAUNCH(PM_, AL_, WALK_) hipLaunchKernelGGL((map_levels<Op, T, PM_, AL_, WALK_>), g, dim3(kThreads), 0, s, q)
+#define EKM_LEV_LAUNCH(PM_, AL_, WALK_) hipLaunchKernelGGL((map_levels<Op, T, PM_, AL_, WALK_>), g, dim3(NT), 0, s, q)
           if (pmode == PM_LEVEL) {
             if (al) EKM_LEV_LAUNCH(PM_LEVEL, true, false); else EKM_LEV_LAUNCH(PM_LEVEL, false, false);
           } else if (pmode == PM_FLAT) {
@@ -921,11 +926,11 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
     return set_error(EKM_ERR_ARG, "EKM_HYBRID_FULL needs full-field operands before it");
   } else if (!bc && aligned) {
     if (unroll >= 2)
-      hipLaunchKernelGGL((map_fields<Op, T, 2>), dim3(grid), dim3(kThreads), 0, s, a, tiles);
+      hipLaunchKernelGGL((map_fields<Op, T, 2>), dim3(grid), dim3(NT), 0, s, a, tiles);
     else
-      hipLaunchKernelGGL((map_fields<Op, T, 1>), dim3(grid), dim3(kThreads), 0, s, a, tiles);
+      hipLaunchKernelGGL((map_fields<Op, T, 1>), dim3(grid), dim3(NT), 0, s, a, tiles);
   } else {
-    const unsigned long long step = (unsigned long long)kThreads * V;  // elements per tile
+    const unsigned long long step = (unsigned long long)NT * V;  // elements per tile
     for (int i = 0; i < NIN; ++i) {
       if (a.mode[i] == EKM_LEVEL_MAJOR) {
         a.step_q[i] = step / a.inner[i];
@@ -934,7 +939,7 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
         a.step_r[i] = step % a.len[i];
       }
     }
-    hipLaunchKernelGGL((map_bcast<Op, T>), dim3(grid), dim3(kThreads), lds_elems * sizeof(T), s, a, tiles);
+    hipLaunchKernelGGL((map_bcast<Op, T>), dim3(grid), dim3(NT), lds_elems * sizeof(T), s, a, tiles);
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return set_error(EKM_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));

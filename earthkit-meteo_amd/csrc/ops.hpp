@@ -9,6 +9,12 @@
 #ifndef EKM_WAVES_PER_EU
 #define EKM_WAVES_PER_EU 1  // one macro for every kernel's launch bounds (a -DEKM_WAVES_PER_EU=N sweep reaches all of them)
 #endif
+#ifndef EKM_THREADS_DEFAULT
+#define EKM_THREADS_DEFAULT 256
+#endif
+#ifndef EKM_TREE_WAVES
+#define EKM_TREE_WAVES 6
+#endif
 #ifndef EKM_WAVES_PER_EU_DEFAULT
 #define EKM_WAVES_PER_EU_DEFAULT EKM_WAVES_PER_EU
 #endif
@@ -182,6 +188,7 @@ struct OpUsesTie<OpWetBulbFromQ<M, T_NEWTON>> {
 template <class Op>
 struct OpTable {
   static constexpr int elems = 0;
+  static constexpr bool vectorized = false;
   template <class T>
   static constexpr int count() {
     return 0;
@@ -194,6 +201,7 @@ template <int METHOD>
 struct BisectTable {
   typedef BisectTable<METHOD> table_type;  // all ops of one theta_e method share one device-resident table
   static constexpr int elems = kBisectLattice;
+  static constexpr bool vectorized = false;
   template <class T>
   static constexpr int count() {
     return kBisectLattice * BisectEntry<METHOD, T>::width;
@@ -203,56 +211,99 @@ struct BisectTable {
     for (int m = tid; m < kBisectLattice; m += nthreads) BisectEntry<METHOD, T>::fill(tab, m);
   }
 };
-typedef BisectTable<EPT_IFS> BisectIfsTable;
-// bolton35 / bolton39: theta_e as the reference forms it, then the table search
-template <int M>
-struct OpTable<OpTOnMa<M, T_BISECT>> : BisectTable<M> {
+// The IFS method: fp32 walks the search tree in heap order with (es, a) pairs + log2 t (thermo_math.hpp::
+// t_on_ma_bisect_heap, 48 KiB), fp64 keeps the lattice table of es.  An op supplies `prep`: te = theta_e*(p/p0)^kappa,
+// its logarithm lte = log2(te/273.16) (fp32 only: LOG) and the pressure, from its own kind of input.
+struct BisectIfsTable {
+  typedef BisectIfsTable table_type;
+  static constexpr int elems = kBisectLattice;
   template <class T>
-  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
-    y[0] = t_on_ma_bisect_tab<M>(x[0], x[1], tab);
+  static constexpr int count() {
+#ifdef EKM_HEAP_FAKE32K
+    return sizeof(T) == 4 ? 2 * kHeapNodes : kBisectLattice * BisectEntry<EPT_IFS, T>::width;
+#else
+    return sizeof(T) == 4 ? 3 * kHeapNodes : kBisectLattice * BisectEntry<EPT_IFS, T>::width;
+#endif
+  }
+  template <class T>
+  EKM_HD static void fill(T* __restrict__ tab, int tid, int nthreads) {
+    for (int m = tid; m < kBisectLattice; m += nthreads) {
+      if constexpr (sizeof(T) == 4)
+        bisect_heap_fill(tab, m);
+      else
+        BisectEntry<EPT_IFS, T>::fill(tab, m);
+    }
   }
 };
-template <int M>
-struct OpTable<OpWetBulbFromTd<M, T_BISECT>> : BisectTable<M> {
+template <class Derived, int NIN_>
+struct BisectIfsOp : BisectIfsTable {
+  static constexpr bool vectorized = true;  // map_kernel.hpp::apply_points hands over the V points of a lane together
+  template <class T, int V>
+  EKM_HD static void apply_v(const T (&x)[V][NIN_], T (&y)[V][1], T, const T* __restrict__ tab, bool all_exact = false) {
+    if constexpr (sizeof(T) == 4) {
+      T te[V], lte[V], p[V], out[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) Derived::template prep<T, true>(x[j], te[j], lte[j], p[j]);
+      t_on_ma_bisect_heap<V>(lte, te, p, tab, out, all_exact);
+#pragma unroll
+      for (int j = 0; j < V; ++j) y[j][0] = out[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        T te, lte, p;
+        Derived::template prep<T, false>(x[j], te, lte, p);
+        y[j][0] = t_on_ma_bisect_ifs_tab(te, p, tab);
+      }
+    }
+  }
   template <class T>
-  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
-    y[0] = t_on_ma_bisect_tab<M>(ept<M, false>(x[0], x[1], x[2]), x[2], tab);
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T rp, const T* __restrict__ tab) {
+    T xx[1][NIN_], yy[1][1];
+#pragma unroll
+    for (int i = 0; i < NIN_; ++i) xx[0][i] = x[i];
+    apply_v<T, 1>(xx, yy, rp, tab);
+    y[0] = yy[0][0];
   }
 };
-template <int M>
-struct OpTable<OpWetBulbFromQ<M, T_BISECT>> : BisectTable<M> {
-  template <class T>
-  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
-    y[0] = t_on_ma_bisect_tab<M>(ept<M, true>(x[0], x[1], x[2]), x[2], tab);
+// te from theta_e and p: te = theta_e*(p/p0)^kappa (thermo.py:1109-1110)
+template <class T, bool LOG>
+EKM_HD void ifs_te_from_ept(T e, T p, T& te, T& lte) {
+  const T kl = T(k::kappa) * m_log2(p * T(1.0 / k::p0));
+  te = e * m_exp2(kl);
+  lte = LOG ? m_log2(e * T(1.0 / 273.16)) + kl : T(0);
+}
+// te from t, q and the LCL temperature: the pressure powers of theta_e (thermo.py:1169-1175) cancel, te = t*exp(K0*q/t_lcl)
+template <class T, bool LOG>
+EKM_HD void ifs_te_from_tq(T t, T q, T tl, T& te, T& lte) {
+  const T xe = T(k::K0_ifs * k::LOG2E) * q * m_rcp(tl);
+  te = t * m_exp2(xe);
+  lte = LOG ? m_log2(t * T(1.0 / 273.16)) + xe : T(0);
+}
+template <>
+struct OpTable<OpTOnMa<EPT_IFS, T_BISECT>> : BisectIfsOp<OpTable<OpTOnMa<EPT_IFS, T_BISECT>>, 2> {
+  template <class T, bool LOG>
+  EKM_HD static void prep(const T* __restrict__ x, T& te, T& lte, T& p) {
+    p = x[1];
+    ifs_te_from_ept<T, LOG>(x[0], p, te, lte);
   }
 };
 template <>
-struct OpTable<OpTOnMa<EPT_IFS, T_BISECT>> : BisectIfsTable {
-  template <class T>
-  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
-    y[0] = t_on_ma_bisect_ifs_tab(x[0] * m_exp2(T(k::kappa) * m_log2(x[1] * T(1.0 / k::p0))), x[1], tab);
+struct OpTable<OpWetBulbFromTd<EPT_IFS, T_BISECT>> : BisectIfsOp<OpTable<OpWetBulbFromTd<EPT_IFS, T_BISECT>>, 3> {
+  template <class T, bool LOG>
+  EKM_HD static void prep(const T* __restrict__ x, T& te, T& lte, T& p) {
+    const T t = x[0], td = x[1];
+    p = x[2];
+    ifs_te_from_tq<T, LOG>(t, q_from_e(es_water(td), p, T(k::eps_default)), lcl_t<LCL_DAVIES>(t, td), te, lte);
   }
 };
 template <>
-struct OpTable<OpWetBulbFromTd<EPT_IFS, T_BISECT>> : BisectIfsTable {
-  template <class T>
-  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
-    // theta_e*(p/p0)^kappa with the two pressure powers cancelled (thermo.py:1169-1175): t*exp(K0*q/t_lcl)
-    const T t = x[0], td = x[1], p = x[2];
-    const T q = q_from_e(es_water(td), p, T(k::eps_default));
-    const T tl = lcl_t<LCL_DAVIES>(t, td);
-    y[0] = t_on_ma_bisect_ifs_tab(t * m_exp2(T(k::K0_ifs * k::LOG2E) * q * m_rcp(tl)), p, tab);
-  }
-};
-template <>
-struct OpTable<OpWetBulbFromQ<EPT_IFS, T_BISECT>> : BisectIfsTable {
-  template <class T>
-  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
-    // the search only needs te = theta_e*(p/p0)^kappa, in which the pressure powers of theta_e (thermo.py:1169-1175)
-    // cancel: te = t*exp(K0*q/t_lcl) -- no log2 / exp2 of the pressure at all
-    const T t = x[0], q = x[1], p = x[2];
-    const T tl = lcl_t<LCL_DAVIES>(t, t_from_es(e_from_q(q, p)));
-    y[0] = t_on_ma_bisect_ifs_tab(t * m_exp2(T(k::K0_ifs * k::LOG2E) * q * m_rcp(tl)), p, tab);
+struct OpTable<OpWetBulbFromQ<EPT_IFS, T_BISECT>> : BisectIfsOp<OpTable<OpWetBulbFromQ<EPT_IFS, T_BISECT>>, 3> {
+  template <class T, bool LOG>
+  EKM_HD static void prep(const T* __restrict__ x, T& te, T& lte, T& p) {
+    // the search only needs te = theta_e*(p/p0)^kappa -- no log2 / exp2 of the pressure at all
+    const T t = x[0], q = x[1];
+    p = x[2];
+    ifs_te_from_tq<T, LOG>(t, q, lcl_t<LCL_DAVIES>(t, t_from_es(e_from_q(q, p))), te, lte);
   }
 };
 
@@ -279,17 +330,21 @@ struct OpTable<OpWbptFromQ<M, T_BISECT>> : BisectTable<M> {
   }
 };
 template <>
-struct OpTable<OpWbptFromTd<EPT_IFS, T_BISECT>> : BisectIfsTable {
-  template <class T>
-  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
-    y[0] = t_on_ma_bisect_ifs_tab(ept<EPT_IFS, false>(x[0], x[1], x[2]), T(k::p0), tab);  // (p/p0)^kappa = 1 at p0
+struct OpTable<OpWbptFromTd<EPT_IFS, T_BISECT>> : BisectIfsOp<OpTable<OpWbptFromTd<EPT_IFS, T_BISECT>>, 3> {
+  template <class T, bool LOG>
+  EKM_HD static void prep(const T* __restrict__ x, T& te, T& lte, T& p) {
+    p = T(k::p0);  // (p/p0)^kappa = 1 at p0: te = theta_e
+    te = ept<EPT_IFS, false>(x[0], x[1], x[2]);
+    lte = LOG ? m_log2(te * T(1.0 / 273.16)) : T(0);
   }
 };
 template <>
-struct OpTable<OpWbptFromQ<EPT_IFS, T_BISECT>> : BisectIfsTable {
-  template <class T>
-  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
-    y[0] = t_on_ma_bisect_ifs_tab(ept<EPT_IFS, true>(x[0], x[1], x[2]), T(k::p0), tab);
+struct OpTable<OpWbptFromQ<EPT_IFS, T_BISECT>> : BisectIfsOp<OpTable<OpWbptFromQ<EPT_IFS, T_BISECT>>, 3> {
+  template <class T, bool LOG>
+  EKM_HD static void prep(const T* __restrict__ x, T& te, T& lte, T& p) {
+    p = T(k::p0);
+    te = ept<EPT_IFS, true>(x[0], x[1], x[2]);
+    lte = LOG ? m_log2(te * T(1.0 / 273.16)) : T(0);
   }
 };
 template <int M>
@@ -354,6 +409,18 @@ struct OpPipelineFull {
 template <>
 struct OpUsesTie<OpPipelineFull> {
   static constexpr bool value = true;
+};
+
+// Threads per workgroup of an op's map kernels, and the waves per SIMD its kernels are compiled for.  The fp32 IFS
+// bisection keeps a 48-KiB search tree in LDS: 512 threads share one copy, so that three workgroups = 24 waves fit a CU
+// (with 256 threads three workgroups were 12 waves, and the search -- a chain of dependent LDS reads -- ran
+// latency-bound at 4.1 ms where the same instruction stream at five workgroups of a 32-KiB table took 3.4;
+// profiles/r04_bisect_tree_walk.txt), and its kernels are held to the 80 registers six waves per SIMD allow.
+template <class Op, class T>
+struct OpThreads {
+  static constexpr bool tree = sizeof(T) == 4 && OpTable<Op>::elems > 0 && OpTable<Op>::vectorized;
+  static constexpr int value = tree ? 512 : EKM_THREADS_DEFAULT;
+  static constexpr int field_waves = tree ? EKM_TREE_WAVES : EKM_WAVES_PER_EU;
 };
 
 // Waves per SIMD a kernel of this op should be compiled for (launch bounds: caps the register allocation).

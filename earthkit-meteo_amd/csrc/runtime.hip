@@ -102,9 +102,10 @@ struct Param {
 static Param g_params[] = {
     {"lev_per_wg", "EKM_LEV_PER_WG", 0, 0, 1024},
     {"hybrid_band_kb", "EKM_HYBRID_BAND_KB", 8192, 4, 1 << 20},
-    {"table_tiles", "EKM_TABLE_TILES", 8, 1, 4096},
+    {"table_tiles", "EKM_TABLE_TILES", 0, 0, 4096},
     {"geo_chunk_levels", "EKM_GEO_CHUNK_LEVELS", 1 << 20, 1, 1 << 20},
     {"f64_plain", "EKM_F64_PLAIN", 0, 0, 1},
+    {"bisect_exact", "EKM_BISECT_EXACT", 0, 0, 1},
 };
 static int param(int i) {
   int v = g_params[i].value.load(std::memory_order_relaxed);
@@ -119,6 +120,7 @@ int tuning_hybrid_band_bytes() { return param(1) * 1024; }
 int tuning_table_tiles() { return param(2); }
 int tuning_geo_chunk_levels() { return param(3); }
 int tuning_f64_plain() { return param(4); }
+int tuning_bisect_exact() { return param(5); }
 
 
 // ---- synthetic atmosphere on the device (SURVEY.md 8d distribution) ---------
@@ -482,7 +484,7 @@ int ekm_set_tuning_param(const char* name, int value) {
       return EKM_OK;
     }
   }
-  return set_error(EKM_ERR_ARG, "set_tuning_param: unknown parameter '%s' (lev_per_wg, hybrid_band_kb, table_tiles, geo_chunk_levels, f64_plain)", name);
+  return set_error(EKM_ERR_ARG, "set_tuning_param: unknown parameter '%s' (lev_per_wg, hybrid_band_kb, table_tiles, geo_chunk_levels, f64_plain, bisect_exact)", name);
 }
 
 int ekm_synth_fill_f32(int dev, void* stream, float* t, float* q, float* p, uint64_t first, size_t n, uint64_t inner,

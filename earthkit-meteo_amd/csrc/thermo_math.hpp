@@ -855,6 +855,144 @@ EKM_HD T t_on_ma_bisect_ifs_tab(T te, T p, const T* __restrict__ tab) {
   return t_on_ma_bisect_tab<EPT_IFS>(te, p, tab);
 }
 
+// ---- the IFS search in fp32 as a walk down the search TREE, most steps decided without a transcendental ---------
+// The 12 halvings visit the nodes of a complete binary tree over the lattice: depth d holds the lattice points
+// m = (2j + 1) * 2^(11-d), j = 0 .. 2^d - 1, and the next node is the left or right child by the sign of the residual.
+// With the nodes stored in heap order (node i, children 2i and 2i + 1) the whole search state is ONE integer and a step
+// is i = i + i + (r > 0): one compare and one add-with-carry, no temperature arithmetic, no index conversion.
+//
+// The reference decides on r = theta_e*exp(G_sat) - th_sat (thermo.py:1075), i.e. after division by the positive
+// (p0/p)^kappa on  r_m = te*2^(g_m) - t_m,  g_m = a_m/w_m,  w_m = p + (eps - 1)*es_m  (one rcp and one exp2 per step;
+// t_on_ma_bisect_tab above).  In logarithms:  r_m > 0  <=>  log2(te) + g_m > log2(t_m)  <=>  a_m > u_m*w_m  with
+// u_m = L_m - lte,  L_m = log2(t_m/273.16) tabulated beside (es_m, a_m)  and  lte = log2(te/273.16), which the callers
+// have anyway (the logarithm of te is formed before te is).  D_m = a_m - u_m*w_m is three fused operations.  Its sign
+// is the sign of the reference's fp32 residual whenever |D_m| exceeds what rounding can move either of the two
+// evaluations: in units of the exponent (D/w = g - u) the fp32 residual carries <= |g|*1.5e-7 + 1.7e-7 (a_m*rcp(w),
+// exp2, the product), the logarithmic form <= 4e-7 + |u|*1.2e-7 (lte, L_m, u*w), and |u| = |g| at the root.  A step
+// with |D_m| <= kHeapTau0*p + kHeapTau1*|a_m| (four times those bounds, p >= w) is AMBIGUOUS and is decided by the
+// reference's own arithmetic, evaluated for the wave -- a wave-uniform branch, taken on about two of the twelve steps
+// of a wave (the last ones, where some lane of the wave stands within a millikelvin of its root).  So every decision is
+// the one t_on_ma_bisect_tab takes, bit for bit, at ~10 plain instructions per step instead of 11 + 2 transcendentals.
+// `all_exact` (tuning parameter bisect_exact) makes every step ambiguous: the stepwise search itself, against which
+// tests/test_gpu_census.py compares the default on every point of the benchmark field.
+//
+// Exactly zero or NaN residuals (the reference then stops moving, resp. turns NaN: `t += sign(r)*dt`) are always
+// ambiguous: the exact branch records the node's temperature (or the NaN) as the lane's final answer, together with the
+// largest es visited so far -- the reference keeps re-evaluating the same point from then on -- for the NaN rule
+// `p - max(es visited) < eps` (thermo.py:192-196, applied once at the end as in t_on_ma_bisect_tab).
+// Table layout (48 KiB of LDS per workgroup): 4096 pairs (es_i, a_i) in heap order, then the 4096 L_i; node 0 unused.
+constexpr int kHeapNodes = kBisectLattice;
+constexpr double kHeapTau0 = 2.5e-6, kHeapTau1 = 1.2e-6;
+
+// lattice index of heap node i at depth d (2^d <= i < 2^(d+1)), d <= 11
+EKM_HD int bisect_heap_lattice(int i, int d) { return (2 * (i - (1 << d)) + 1) << (11 - d); }
+
+EKM_HD void bisect_heap_fill(float* __restrict__ tab, int i) {
+  float es = 0.0f, a = 0.0f, L = 0.0f;
+  if (i >= 1) {
+    int d = 0;
+    while ((2 << d) <= i) ++d;
+    const float t = bisect_lattice_t<float>(bisect_heap_lattice(i, d));
+    es = es_mixed(t);
+    a = bisect_second<EPT_IFS>(es, 1.0f / t);  // IEEE division: once per device
+    L = (float)m_log2(double(t) * (1.0 / 273.16));
+  }
+  tab[2 * i] = es;
+  tab[2 * i + 1] = a;
+#ifndef EKM_HEAP_FAKE32K
+  tab[2 * kHeapNodes + i] = L;
+#else
+  (void)L;
+#endif
+}
+
+// heap child of `node` by the sign of the residual: 2*node + (r > 0) -- one compare and one add-with-carry
+EKM_HD unsigned bisect_heap_child(unsigned node, float r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned next;
+  asm("v_cmp_lt_f32 vcc, 0, %2\n\tv_addc_co_u32 %0, vcc, %1, %1, vcc" : "=v"(next) : "v"(node), "v"(r) : "vcc");
+  return next;
+#else
+  return node + node + (r > 0.0f ? 1u : 0u);
+#endif
+}
+
+template <int V>
+EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], const float (&p)[V],
+                                const float* __restrict__ tab, float (&out)[V], bool all_exact = false) {
+  // esmax: the largest es visited, kept as its bit pattern -- the table's es are finite and >= 0, so their bit patterns
+  // order like the values and the running maximum is ONE v_max_u32 (v_max_f32 wants a canonicalising copy of a freshly
+  // loaded operand in front of it)
+  unsigned node[V], esmax[V], esfix[V];
+  float thr0[V], tfix[V];  // tfix: the final answer of a lane whose residual came out exactly zero or NaN; 0 = none yet
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    node[j] = 1u;
+    esmax[j] = esfix[j] = 0u;
+    thr0[j] = float(kHeapTau0) * p[j];
+    tfix[j] = 0.0f;
+  }
+  const char* __restrict__ pairs = reinterpret_cast<const char*>(tab);
+#ifdef EKM_HEAP_FAKE32K  // timing experiment only (WRONG results): the logarithms read from inside the pair table, 32 KiB of LDS
+  const char* __restrict__ logs = pairs;
+#else
+  const char* __restrict__ logs = pairs + 8 * kHeapNodes;
+#endif
+#pragma unroll
+  for (int d = 0; d < 12; ++d) {
+    float es[V], a[V], w[V], D[V];
+    bool amb[V], any = false;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      const f2 ea = *reinterpret_cast<const f2*>(pairs + (node[j] << 3));  // one ds_read_b64
+      es[j] = ea[0];
+      a[j] = ea[1];
+#else
+      es[j] = tab[2 * node[j]];
+      a[j] = tab[2 * node[j] + 1];
+#endif
+      const float u = *reinterpret_cast<const float*>(logs + (node[j] << 2)) - lte[j];
+      w[j] = m_fma(float(k::eps - 1), es[j], p[j]);
+      D[j] = m_fnma(u, w[j], a[j]);
+      const unsigned eb = __builtin_bit_cast(unsigned, es[j]);
+      esmax[j] = esmax[j] > eb ? esmax[j] : eb;
+      amb[j] = !(__builtin_fabsf(D[j]) > m_fma(__builtin_fabsf(a[j]), float(kHeapTau1), thr0[j])) || all_exact;  // NaN: ambiguous
+      any = any || amb[j];
+    }
+    if (EKM_ANY(any)) {  // the reference's own residual for the lanes that need it
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        if (amb[j]) {
+          const float tm = bisect_lattice_t<float>(bisect_heap_lattice((int)node[j], d));
+          const float r = m_fms(te[j], m_exp2(a[j] * m_rcp(w[j])), tm);
+          D[j] = r;
+          if (!(r < 0.0f || r > 0.0f) && tfix[j] == 0.0f) {  // zero: the reference stays on this point; NaN: it turns NaN
+            tfix[j] = r == 0.0f ? tm : r;  // (lattice temperatures are >= 133 K: never the "none" value)
+            esfix[j] = esmax[j];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) node[j] = bisect_heap_child(node[j], D[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    // the leaf (4096 <= node < 8192): t0 + (M - 4096)*120/4096 with M = 2*(node - 4096) + 1, i.e. 2*node - 12287 half
+    // steps from t0 -- exactly the reference's accumulated fp32 sum
+    float t = float(k::T0 - 20) + float(2 * (int)node[j] - (3 * kHeapNodes - 1)) * float(120.0 / 4096);
+    unsigned em = esmax[j];
+    if (tfix[j] != 0.0f) {
+      t = tfix[j];
+      em = esfix[j];
+    }
+    if ((p[j] - __builtin_bit_cast(float, em)) < float(k::eps_default)) t = nan_v<float>();
+    out[j] = t;
+  }
+}
+
 template <int METHOD, class T>
 EKM_HD T t_on_ma_bisect(T e, T p) {
   if (METHOD == EPT_IFS) return t_on_ma_bisect_ifs(e, p);

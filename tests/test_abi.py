@@ -101,8 +101,10 @@ def test_tuning_parameters_by_name_need_no_gpu():
     lib = _ffi.lib()
     assert lib.ekm_set_tuning_param(b"hybrid_band_kb", 4096) == 0 and lib.ekm_set_tuning_param(b"hybrid_band_kb", 8192) == 0
     assert lib.ekm_set_tuning_param(b"geo_chunk_levels", 1 << 20) == 0 and lib.ekm_set_tuning_param(b"lev_per_wg", 0) == 0
-    assert lib.ekm_set_tuning_param(b"table_tiles", 16) == 0
-    assert lib.ekm_set_tuning_param(b"table_tiles", 0) == _ffi.EKM_ERR_ARG and b"table_tiles" in lib.ekm_last_error()
+    assert lib.ekm_set_tuning_param(b"table_tiles", 16) == 0 and lib.ekm_set_tuning_param(b"table_tiles", 0) == 0  # 0 = by op
+    assert lib.ekm_set_tuning_param(b"table_tiles", -1) == _ffi.EKM_ERR_ARG and b"table_tiles" in lib.ekm_last_error()
+    assert lib.ekm_set_tuning_param(b"bisect_exact", 1) == 0 and lib.ekm_set_tuning_param(b"bisect_exact", 0) == 0
+    assert lib.ekm_set_tuning_param(b"f64_plain", 2) == _ffi.EKM_ERR_ARG
     assert lib.ekm_set_tuning_param(b"no_such_parameter", 1) == _ffi.EKM_ERR_ARG
     assert b"unknown parameter" in lib.ekm_last_error()
     assert lib.ekm_set_tuning_param(None, 1) == _ffi.EKM_ERR_ARG
