@@ -674,12 +674,12 @@ def judge_sample(args, smp):
         is_tw = args.workload == "wetbulb" or (args.workload == "full" and k == 5)
         if is_tw and ((r > tol) | nanmm).any():
             # hPa-level pressures (hybrid top levels): a miss counts unless the reference's OWN one-step Newton amplifies
-            # input perturbations enough to explain it (oracle/conditioning.py::newton_amplification, fp64 oracle only)
+            # input perturbations enough to explain it (oracle/conditioning.py::newton_misses_explained, fp64 oracle only)
             from oracle import conditioning
 
             miss = np.flatnonzero((r > tol) | nanmm)
-            kap = conditioning.newton_amplification(ht[miss], hq[miss], hp[miss])
-            ok = np.isinf(kap) | (~nanmm[miss] & (r[miss] <= 8.0 * kap * 2.0 ** -24))
+            fin, edge = conditioning.newton_misses_explained(ht[miss], hq[miss], hp[miss], g[miss], w[miss], tol)
+            ok = fin | edge
             explained += int(ok.sum())
             r[miss[ok]] = 0.0
             nanmm[miss[ok]] = False

@@ -211,6 +211,29 @@ struct BisectTable {
     for (int m = tid; m < kBisectLattice; m += nthreads) BisectEntry<METHOD, T>::fill(tab, m);
   }
 };
+// bolton35 / bolton39: theta_e as the reference forms it, then the table search
+template <int M>
+struct OpTable<OpTOnMa<M, T_BISECT>> : BisectTable<M> {
+  template <class T>
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
+    y[0] = t_on_ma_bisect_tab<M>(x[0], x[1], tab);
+  }
+};
+template <int M>
+struct OpTable<OpWetBulbFromTd<M, T_BISECT>> : BisectTable<M> {
+  template <class T>
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
+    y[0] = t_on_ma_bisect_tab<M>(ept<M, false>(x[0], x[1], x[2]), x[2], tab);
+  }
+};
+template <int M>
+struct OpTable<OpWetBulbFromQ<M, T_BISECT>> : BisectTable<M> {
+  template <class T>
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
+    y[0] = t_on_ma_bisect_tab<M>(ept<M, true>(x[0], x[1], x[2]), x[2], tab);
+  }
+};
+
 // The IFS method: fp32 walks the search tree in heap order with (es, a) pairs + log2 t (thermo_math.hpp::
 // t_on_ma_bisect_heap, 48 KiB), fp64 keeps the lattice table of es.  An op supplies `prep`: te = theta_e*(p/p0)^kappa,
 // its logarithm lte = log2(te/273.16) (fp32 only: LOG) and the pressure, from its own kind of input.
@@ -355,6 +378,21 @@ template <int M>
 struct OpUsesTie<OpWbptFromQ<M, T_NEWTON>> {
   static constexpr bool value = true;
 };
+// every bisection entry point runs on an LDS table (without its OpTable an op silently takes the table-free statement,
+// 2x slower and otherwise indistinguishable)
+static_assert(OpTable<OpTOnMa<EPT_IFS, T_BISECT>>::elems > 0 && OpTable<OpTOnMa<EPT_BOLTON35, T_BISECT>>::elems > 0 &&
+                  OpTable<OpTOnMa<EPT_BOLTON39, T_BISECT>>::elems > 0 && OpTable<OpWetBulbFromTd<EPT_IFS, T_BISECT>>::elems > 0 &&
+                  OpTable<OpWetBulbFromTd<EPT_BOLTON35, T_BISECT>>::elems > 0 && OpTable<OpWetBulbFromTd<EPT_BOLTON39, T_BISECT>>::elems > 0 &&
+                  OpTable<OpWetBulbFromQ<EPT_IFS, T_BISECT>>::elems > 0 && OpTable<OpWetBulbFromQ<EPT_BOLTON35, T_BISECT>>::elems > 0 &&
+                  OpTable<OpWetBulbFromQ<EPT_BOLTON39, T_BISECT>>::elems > 0 && OpTable<OpWbptFromTd<EPT_IFS, T_BISECT>>::elems > 0 &&
+                  OpTable<OpWbptFromTd<EPT_BOLTON35, T_BISECT>>::elems > 0 && OpTable<OpWbptFromTd<EPT_BOLTON39, T_BISECT>>::elems > 0 &&
+                  OpTable<OpWbptFromQ<EPT_IFS, T_BISECT>>::elems > 0 && OpTable<OpWbptFromQ<EPT_BOLTON35, T_BISECT>>::elems > 0 &&
+                  OpTable<OpWbptFromQ<EPT_BOLTON39, T_BISECT>>::elems > 0,
+              "a bisection op lost its lookup table");
+static_assert(OpTable<OpWetBulbFromQ<EPT_IFS, T_BISECT>>::vectorized && !OpTable<OpWetBulbFromQ<EPT_BOLTON35, T_BISECT>>::vectorized &&
+                  OpTable<OpWetBulbFromQ<EPT_IFS, T_NEWTON>>::elems == 0,
+              "table traits");
+
 // thermo.py:1678-1707
 EKM_OP(OpGasConstant, 1, 1, y[0] = m_fma(T(k::Rv - k::Rd), x[0], T(k::Rd));)
 

@@ -49,18 +49,22 @@ def job(job):
                          worst_over=float(r[r > tol].max()) if (r > tol).any() else 0.0,
                          reference_fp32_vs_fp64_nan_mismatch=int((np.isnan(w64) != np.isnan(w_true)).sum()))
             # every miss is classified by how strongly the reference's OWN algorithm amplifies input perturbations
-            # there (oracle/conditioning.py::newton_amplification, fp64 oracle only): explained iff the deviation is
-            # within 8 x kappa x 2^-24, or the point sits on a NaN / regime edge (kappa = inf)
+            # there (oracle/conditioning.py::newton_misses_explained, fp64 oracle only): explained iff the deviation is
+            # within 8 x kappa x 2^-24, or the point sits on a NaN / regime edge (kappa = inf) AND the value under test is
+            # one of the outcomes that edge offers (the fp64 oracle at the point or at a 1e-6 perturbation of an input)
             nanmm = np.isnan(g64) != np.isnan(w64)
             miss = np.flatnonzero((r > tol) | nanmm)
             expl = np.zeros(miss.size, bool)
+            expl_finite = expl_edge = expl
             if miss.size:
-                kap = conditioning.newton_amplification(t[miss], q[miss], p[miss])
-                expl = np.isinf(kap) | (~nanmm[miss] & (r[miss] <= 8.0 * kap * 2.0 ** -24))
+                expl_finite, expl_edge = conditioning.newton_misses_explained(t[miss], q[miss], p[miss], g64[miss], w64[miss], tol)
+                expl = expl_finite | expl_edge
             # ... or it is a Davies-Jones regime tie that the fp32 reference's own rounding flipped: the point lies in
             # the 1e-5 regime band and the output under test sides with the fp64 reference
             flip = ~expl & band5[miss] & ~nanmm[miss] & (r64[miss] <= tol)
-            entry.update(over_explained_by_amplification=int(expl.sum()), over_regime_flip_of_the_fp32_reference=int(flip.sum()),
+            entry.update(over_explained_by_amplification=int(expl.sum()), over_explained_finite_kappa=int(expl_finite.sum()),
+                         over_explained_on_a_nan_edge=int((expl_edge & ~expl_finite).sum()),
+                         over_regime_flip_of_the_fp32_reference=int(flip.sum()),
                          over_unexplained=int((~(expl | flip)).sum()))
         res.append(entry)
     return res

@@ -73,17 +73,19 @@ def newton_regime_boundary(func, inputs, kwargs, thresh):
         return dist <= thresh
 
 
-def newton_amplification(t, q, p, h=1e-6):
+def newton_amplification(t, q, p, h=1e-6, return_candidates=False):
     """How strongly the reference's own one-step Newton wet-bulb (ifs) amplifies a relative perturbation of its
     inputs, on the fp64 oracle: kappa = max over (t, q, p) of |tw(x(1+h)) - tw(x(1-h))| / (2 h |tw(x)|); inf where a
     perturbed evaluation changes NaN-ness (the point sits on the edge of the p - es < eps / tw <= 0 NaN regions or on
     a regime threshold).  At hPa-level pressures (p < ~60 Pa: es(tw) ~ p, qs ~ 1) the single Newton step is far
     from converged and kappa reaches 1e3-1e6: an fp32 rounding of an intermediate (6e-8) then shows up at 1e-4 and
-    beyond in ANY fp32 evaluation, the reference's own included.  Identified from the oracle alone."""
+    beyond in ANY fp32 evaluation, the reference's own included.  Identified from the oracle alone.
+    `return_candidates`: also the seven fp64 values themselves, [7, n]: the unperturbed one and the six perturbed."""
     with np.errstate(all="ignore"):
         x = [np.asarray(a, dtype=np.float64) for a in (t, q, p)]
         base = orc.wet_bulb_temperature_from_specific_humidity(*x, "ifs", "newton")
         kappa = np.zeros(base.shape)
+        cands = [base]
         for i in range(3):
             lo, hi = list(x), list(x)
             lo[i], hi[i] = x[i] * (1.0 - h), x[i] * (1.0 + h)
@@ -92,4 +94,35 @@ def newton_amplification(t, q, p, h=1e-6):
             k = np.abs(b - a) / (2.0 * h * np.abs(base))
             k = np.where(np.isnan(a) | np.isnan(b) | np.isnan(base), np.inf, k)
             kappa = np.maximum(kappa, k)
-    return kappa
+            cands += [a, b]
+    return (kappa, np.stack(cands)) if return_candidates else kappa
+
+
+def newton_misses_explained(t, q, p, got, want, tol, h=1e-6):
+    """Which deviations of a one-step Newton wet-bulb `got` from the reference's `want` (same dtype run) the reference's
+    own conditioning explains -- from the fp64 oracle alone, never from `got`.  Returns two masks over the points:
+      * finite kappa: the deviation is within 8 x kappa x 2^-24 (kappa: newton_amplification);
+      * on a NaN / regime edge (kappa = inf: a 1e-6 perturbation of an input changes the NaN-ness of the fp64 result): the
+        value under test must BE one of the outcomes that edge offers -- NaN where the fp64 oracle or one of its six
+        perturbed evaluations is NaN, or a finite value within max(tol, 8 x kappa_f x 2^-24) of one of the finite ones,
+        kappa_f being the amplification seen among those finite evaluations (their spread over the perturbation).
+    A point outside both masks is a real miss."""
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    with np.errstate(all="ignore"):
+        nanmm = np.isnan(got) != np.isnan(want)
+        r = np.abs(got - want) / np.abs(want)
+        r = np.where(np.isfinite(r), r, 0.0)
+        kap, cands = newton_amplification(t, q, p, h, return_candidates=True)
+        edge = np.isinf(kap)
+        finite = ~edge & ~nanmm & (r <= 8.0 * np.where(edge, 0.0, kap) * 2.0 ** -24)
+        cn = np.isnan(cands)
+        lo = np.min(np.where(cn, np.inf, cands), axis=0)
+        hi = np.max(np.where(cn, -np.inf, cands), axis=0)
+        some = np.isfinite(lo)
+        mid = np.where(some, 0.5 * (np.abs(lo) + np.abs(hi)), 1.0)
+        kap_f = np.where(some, (hi - lo) / (2.0 * h * mid), 0.0)  # spread of the finite outcomes per unit perturbation
+        bar = np.maximum(tol, 8.0 * kap_f * 2.0 ** -24)
+        dist = np.min(np.where(cn, np.inf, np.abs(cands - got[None, :]) / np.abs(cands)), axis=0)
+        on_edge = edge & np.where(np.isnan(got), cn.any(axis=0), dist <= bar)
+    return finite, on_edge

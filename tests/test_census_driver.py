@@ -55,3 +55,38 @@ def test_newton_amplification_separates_hpa_level_points_from_tropospheric_ones(
     tt = np.full(2000, 232.0) + np.linspace(-6, 6, 2000)
     k2 = conditioning.newton_amplification(tt, np.full(2000, 3e-6), np.full(2000, 16.0))
     assert np.median(k2[np.isfinite(k2)]) > 50
+
+
+def test_a_miss_on_a_nan_edge_must_be_one_of_the_outcomes_the_edge_offers():
+    """kappa = inf (a 1e-6 perturbation of an input changes the NaN-ness of the fp64 oracle) used to
+    accept ANY value.  Now the value under test must be NaN where the oracle or one of its perturbed evaluations is, or
+    a finite value near one of the finite ones -- garbage on such a point is a real miss."""
+    from oracle import conditioning
+
+    # 16 Pa, dry: find where the one-step Newton wet-bulb of the fp64 oracle turns NaN along t (the p - es < eps edge),
+    # then sample within +-0.5 mK of it -- closer than the 1e-6 relative perturbation (0.23 mK) the rule probes with
+    coarse = np.full(4000, 232.0) + np.linspace(-8, 8, 4000)
+    base = orc.wet_bulb_temperature_from_specific_humidity(coarse, np.full(4000, 3e-6), np.full(4000, 16.0), "ifs", "newton")
+    flips = np.flatnonzero(np.isnan(base[1:]) != np.isnan(base[:-1]))
+    assert flips.size, "the sweep crosses no NaN edge: pick another column"
+    lo, hi = coarse[flips[0]], coarse[flips[0] + 1]
+    for _ in range(40):  # bisect the edge down to rounding
+        mid = 0.5 * (lo + hi)
+        v = orc.wet_bulb_temperature_from_specific_humidity(np.array([lo, mid]), np.full(2, 3e-6), np.full(2, 16.0), "ifs", "newton")
+        lo, hi = (mid, hi) if np.isnan(v[0]) == np.isnan(v[1]) else (lo, mid)
+    n = 2000
+    t = lo + np.linspace(-5e-4, 5e-4, n)
+    q, p = np.full(n, 3e-6), np.full(n, 16.0)
+    kap, cands = conditioning.newton_amplification(t, q, p, return_candidates=True)
+    edge = np.flatnonzero(np.isinf(kap) & np.isfinite(cands).any(axis=0) & np.isnan(cands).any(axis=0))
+    assert edge.size > 0, "the sweep crosses no NaN edge: pick another column"
+    te, qe, pe = t[edge], q[edge], p[edge]
+    want = orc.wet_bulb_temperature_from_specific_humidity(te, qe, pe, "ifs", "newton")
+    first_finite = np.array([c[np.isfinite(c)][0] for c in cands[:, edge].T])
+    for got, ok in ((np.full(edge.size, np.nan), True),             # NaN: some outcome of the edge is NaN
+                    (first_finite * (1 + 2e-5), True),              # a finite outcome of the edge, within the bar
+                    (np.full(edge.size, 123.456), False),           # garbage
+                    (first_finite + 50.0, False)):                  # a finite value far from every outcome
+        fin, on_edge = conditioning.newton_misses_explained(te, qe, pe, got, want, 1e-4)
+        assert not fin.any()                                        # kappa = inf: never through the finite-kappa rule
+        assert on_edge.all() == ok and on_edge.any() == ok, (got[:3], on_edge[:8])

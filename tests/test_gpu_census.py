@@ -181,7 +181,9 @@ def test_census_p5_hybrid_levels_all_137_levels(ek, tq):
     p_mid = 0.5 * (A[:-1] + A[1:]) + 0.5 * (B[:-1] + B[1:]) * 101325.0
     _report("census P5 fp32, hybrid levels formed in-kernel, 137 levels (1 Pa ... surface)", total, N3, time.time() - t0,
             extra=(f"; tw: levels with a miss {hit[:1]}..{hit[-1:]} (p <= {max([p_mid[k] for k in hit], default=0):.0f} Pa), "
-                   f"misses explained by the reference's own amplification {e['over_explained_by_amplification']}, "
+                   f"misses explained by the reference's own amplification {e['over_explained_by_amplification']} "
+                   f"({e['over_explained_finite_kappa']} within 8 x kappa x 2^-24, {e['over_explained_on_a_nan_edge']} on a NaN edge of the "
+                   f"fp64 oracle and equal to one of the outcomes that edge offers), "
                    f"regime ties flipped by the fp32 reference's own rounding (ours = the fp64 reference) "
                    f"{e['over_regime_flip_of_the_fp32_reference']} of {e['band_1e5']} boundary points, "
                    f"unexplained {e['over_unexplained']}; the reference's fp32 vs its fp64 beyond 1e-4: "
