@@ -24,6 +24,8 @@ run p3_hybrid       p3:hybrid:f32:137           --workload p3 --pmode hybrid
 run wetbulb_hybrid  wetbulb:hybrid:f32:137      --workload wetbulb --pmode hybrid
 run theta_hybrid    theta:hybrid:f32:137        --workload theta --pmode hybrid
 run geopotential    geopotential:hybrid:f32:137 --workload geopotential
+run full_f64        full:field:f64:137          --dtype f64
+run wetbulb_f64     wetbulb:field:f64:137       --workload wetbulb --dtype f64
 for wl in full wetbulb wetbulb_bisect wetbulb_bisect_bolton35 wetbulb_bisect_bolton39 p3; do
   tools/profile_valu.sh "$G/valu_$wl" --workload $wl > "$G/valu_$wl.log" 2>&1 && python3 tools/summarize_valu.py "$G/valu_$wl" $wl "profiles/${R}_valu_counters.json"
 done
