@@ -158,7 +158,13 @@ __device__ __forceinline__ void apply_points(const T (&x)[V][Op::NIN], T (&y)[V]
     for (int j = 0; j < V; ++j) {
 #pragma unroll
       for (int i = 0; i < Op::NIN; ++i) xf[j][i] = fdouble(x[j][i]);
-      op_apply_as<Op, fdouble>(xf[j], yf[j], fdouble(rp), reinterpret_cast<const fdouble*>(tab));
+    }
+    if constexpr (OpTable<Op>::elems > 0 && OpTable<Op>::vectorized)  // the bisection's tree walk: the V points together
+      OpTable<Op>::template apply_v<fdouble, V>(xf, yf, fdouble(rp), reinterpret_cast<const fdouble*>(tab), (switches & 2) != 0);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      if constexpr (!(OpTable<Op>::elems > 0 && OpTable<Op>::vectorized))
+        op_apply_as<Op, fdouble>(xf[j], yf[j], fdouble(rp), reinterpret_cast<const fdouble*>(tab));
 #pragma unroll
       for (int o = 0; o < Op::NOUT; ++o) {
         y[j][o] = yf[j][o].v;
@@ -604,7 +610,7 @@ int tuning_bisect_exact();   // fp32 IFS bisection: 1 = the reference's residual
 int tuning_f64_plain();      // fp64 map kernels: 1 = every lane redone in plain double (EKM_F64_PLAIN, default 0)
 int tuning_geo_chunk_levels();  // levels per launch of the geopotential column scan (EKM_GEO_CHUNK_LEVELS, default: all in one launch)
 
-constexpr unsigned kMaxLdsBytes = 64 * 1024;
+constexpr unsigned kMaxLdsBytes = 32 * 1024;  // staged level vectors (dynamic LDS); an op's own table (static, up to 80 KiB) comes on top
 
 // Per-device, once: compute the op's table into its __device__ array -- WITHOUT a host wait, so that a launch function
 // stays free of synchronisation (it may run while another stream or thread of the process is capturing):
@@ -780,11 +786,10 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
     if (reinterpret_cast<uintptr_t>(outs[o]) % 16) aligned = false;
   }
   a.vec_ok = aligned ? 1 : 0;
-  // the op's own per-workgroup table (static LDS, OpTable) shares the 64 KiB with the staged level vectors
-  constexpr size_t kTableBytes = (size_t)OpTable<Op>::template count<T>() * sizeof(T);
-  if ((size_t)lds_elems * sizeof(T) + kTableBytes > kMaxLdsBytes)
-    return set_error(EKM_ERR_ARG, "level vectors need %zu B of LDS (max %zu beside this op's %zu-B table)",
-                     (size_t)lds_elems * sizeof(T), (size_t)kMaxLdsBytes - kTableBytes, kTableBytes);
+  // staged level vectors: at most 32 KiB of dynamic LDS (what the host layer hands over at most); the op's own
+  // per-workgroup table is static LDS on top of that (the CU has 160 KiB)
+  if ((size_t)lds_elems * sizeof(T) > kMaxLdsBytes)
+    return set_error(EKM_ERR_ARG, "level vectors need %zu B of LDS (max %zu)", (size_t)lds_elems * sizeof(T), (size_t)kMaxLdsBytes);
 
   const unsigned long long nchunk = (n + V - 1) / V;
   const unsigned long long ntile = (nchunk + NT - 1) / NT;

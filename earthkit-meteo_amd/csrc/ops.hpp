@@ -240,21 +240,25 @@ struct OpTable<OpWetBulbFromQ<M, T_BISECT>> : BisectTable<M> {
 struct BisectIfsTable {
   typedef BisectIfsTable table_type;
   static constexpr int elems = kBisectLattice;
+  // fp32: the tree (4096 (es, a) pairs + 4096 log2 t: 48 KiB).  fp64: the lattice table of es in double (32 KiB) and,
+  // behind it, the SAME fp32 tree for the sign tests (80 KiB).
   template <class T>
   static constexpr int count() {
 #ifdef EKM_HEAP_FAKE32K
     return sizeof(T) == 4 ? 2 * kHeapNodes : kBisectLattice * BisectEntry<EPT_IFS, T>::width;
 #else
-    return sizeof(T) == 4 ? 3 * kHeapNodes : kBisectLattice * BisectEntry<EPT_IFS, T>::width;
+    return sizeof(T) == 4 ? 3 * kHeapNodes : kBisectLattice * BisectEntry<EPT_IFS, T>::width + 3 * kHeapNodes / 2;
 #endif
   }
   template <class T>
   EKM_HD static void fill(T* __restrict__ tab, int tid, int nthreads) {
     for (int m = tid; m < kBisectLattice; m += nthreads) {
-      if constexpr (sizeof(T) == 4)
+      if constexpr (sizeof(T) == 4) {
         bisect_heap_fill(tab, m);
-      else
+      } else {
         BisectEntry<EPT_IFS, T>::fill(tab, m);
+        bisect_heap_fill(reinterpret_cast<float*>(tab + kBisectLattice), m);
+      }
     }
   }
 };
@@ -270,13 +274,13 @@ struct BisectIfsOp : BisectIfsTable {
       t_on_ma_bisect_heap<V>(lte, te, p, tab, out, all_exact);
 #pragma unroll
       for (int j = 0; j < V; ++j) y[j][0] = out[j];
-    } else {
+    } else {  // double / fd64: sign tests in fp32 on the tree behind the fp64 table, ambiguous steps in T
+      T te[V], lte[V], p[V], out[V];
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        T te, lte, p;
-        Derived::template prep<T, false>(x[j], te, lte, p);
-        y[j][0] = t_on_ma_bisect_ifs_tab(te, p, tab);
-      }
+      for (int j = 0; j < V; ++j) Derived::template prep<T, true>(x[j], te[j], lte[j], p[j]);
+      t_on_ma_bisect_heap64<T, V>(lte, te, p, reinterpret_cast<const float*>(tab + kBisectLattice), tab, out, all_exact);
+#pragma unroll
+      for (int j = 0; j < V; ++j) y[j][0] = out[j];
     }
   }
   template <class T>
@@ -456,9 +460,10 @@ struct OpUsesTie<OpPipelineFull> {
 // profiles/r04_bisect_tree_walk.txt), and its kernels are held to the 80 registers six waves per SIMD allow.
 template <class Op, class T>
 struct OpThreads {
-  static constexpr bool tree = sizeof(T) == 4 && OpTable<Op>::elems > 0 && OpTable<Op>::vectorized;
+  static constexpr bool tree = OpTable<Op>::elems > 0 && OpTable<Op>::vectorized;
   static constexpr int value = tree ? 512 : EKM_THREADS_DEFAULT;
-  static constexpr int field_waves = tree ? EKM_TREE_WAVES : EKM_WAVES_PER_EU;
+  // fp32: 48 KiB, three workgroups = six waves per SIMD (<= 80 registers); fp64: 80 KiB, two workgroups = four waves
+  static constexpr int field_waves = tree ? (sizeof(T) == 4 ? EKM_TREE_WAVES : 4) : EKM_WAVES_PER_EU;
 };
 
 // Waves per SIMD a kernel of this op should be compiled for (launch bounds: caps the register allocation).

@@ -993,6 +993,91 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
   }
 }
 
+// The same walk for the fp64 kernels (T = double or fd64): the sign tests run in fp32 on the SAME fp32 tree (the inputs
+// rounded to float: their rounding, <= 6e-8 relative, is far inside the tolerance band), and a step whose test is within
+// the band is decided by the fp64 residual of t_on_ma_bisect_tab -- es from the fp64 lattice table, ONE software
+// reciprocal, one software exp2, ~60 fp64 operations -- which the stepwise fp64 search paid at every one of its twelve
+// steps and this walk pays on the few ambiguous ones.  The band is the fp32 one (the fp64 residual's own rounding is
+// nine orders below it), so outside it the fp32 sign IS the sign of the fp64 residual.
+// Largest es visited (the NaN rule): es grows with t, so it is es of the hottest node visited -- the first node the
+// walk left DOWNWARDS, or the deepest node if it never did -- read once at the end from the fp64 table.
+template <class T, int V>
+EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (&p)[V], const float* __restrict__ heap,
+                                  const T* __restrict__ es_tab, T (&out)[V], bool all_exact = false) {
+  unsigned node[V];
+  int kfix[V];  // step at which the residual came out exactly zero / NaN (the reference then stays / turns NaN); -1 = never
+  float ltef[V], pf[V], thr0[V];
+  T tfix[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    node[j] = 1u;
+    kfix[j] = -1;
+    ltef[j] = (float)lte[j];
+    pf[j] = (float)p[j];
+    thr0[j] = float(1.5 * kHeapTau0) * pf[j];
+    tfix[j] = T(0.0);
+  }
+  const char* __restrict__ pairs = reinterpret_cast<const char*>(heap);
+  const char* __restrict__ logs = pairs + 8 * kHeapNodes;
+#pragma unroll
+  for (int d = 0; d < 12; ++d) {
+    float D[V];
+    bool amb[V], any = false;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      const f2 ea = *reinterpret_cast<const f2*>(pairs + (node[j] << 3));
+      const float es = ea[0], a = ea[1];
+#else
+      const float es = heap[2 * node[j]], a = heap[2 * node[j] + 1];
+#endif
+      const float u = *reinterpret_cast<const float*>(logs + (node[j] << 2)) - ltef[j];
+      const float w = m_fma(float(k::eps - 1), es, pf[j]);
+      D[j] = m_fnma(u, w, a);
+      amb[j] = !(__builtin_fabsf(D[j]) > m_fma(__builtin_fabsf(a), float(1.5 * kHeapTau1), thr0[j])) || all_exact;
+      any = any || amb[j];
+    }
+    if (EKM_ANY(any)) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        if (amb[j]) {
+          const int m = bisect_heap_lattice((int)node[j], d);
+          const T tm = bisect_lattice_t<T>(m), es = es_tab[m];
+          const T v = m_fma(T(k::eps - 1), es, p[j]);
+          const T r1 = m_rcp(v * tm);  // 1/(v*t) gives both 1/v and 1/t (t_on_ma_bisect_tab)
+          const T g = bisect_second<EPT_IFS>(es, r1 * v) * (r1 * tm);
+          const T r = m_fms(te[j], m_exp2(g), tm);
+          D[j] = r > T(0) ? 1.0f : -1.0f;
+          if (!(r < T(0) || r > T(0)) && kfix[j] < 0) {
+            kfix[j] = d;
+            tfix[j] = r == T(0) ? tm : r;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) node[j] = bisect_heap_child(node[j], D[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    T t = T(k::T0 - 20) + T(2 * (int)node[j] - (3 * kHeapNodes - 1)) * T(120.0 / 4096);
+    // hottest node visited: among the nodes of depth 0 .. last (last = 11, or the step the search got stuck at), the
+    // first one left downwards (a 0 bit of the path), else the node of depth `last`
+    const int last = kfix[j] >= 0 ? kfix[j] : 11;
+    const unsigned path = node[j] & (unsigned)(kHeapNodes - 1);  // the 12 decisions, the first one in bit 11
+    int dmax = last;
+#pragma unroll
+    for (int d = 11; d >= 0; --d)
+      if (d < last && !((path >> (11 - d)) & 1u)) dmax = d;
+    const unsigned nmax = (1u << dmax) | (path >> (12 - dmax));
+    const T esmax = es_tab[bisect_heap_lattice((int)nmax, dmax)];
+    if (kfix[j] >= 0) t = tfix[j];
+    if ((p[j] - esmax) < T(k::eps_default)) t = nan_v<T>();
+    out[j] = t;
+  }
+}
+
 template <int METHOD, class T>
 EKM_HD T t_on_ma_bisect(T e, T p) {
   if (METHOD == EPT_IFS) return t_on_ma_bisect_ifs(e, p);

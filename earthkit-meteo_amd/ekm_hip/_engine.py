@@ -23,7 +23,7 @@ from .device import DeviceArray, current_device, current_stream
 from .vertical import HybridPressure
 
 _F32, _F64 = np.dtype(np.float32), np.dtype(np.float64)
-_MAX_LDS_BYTES = 32 * 1024  # of the kernels' 64 KiB: an op's own LDS table (bisection: up to 32 KiB in fp64) shares it
+_MAX_LDS_BYTES = 32 * 1024  # staged level vectors per workgroup (csrc/map_kernel.hpp::kMaxLdsBytes); an op's own table comes on top
 _MIN_VEC = 4  # a LEVEL operand must span at least one 16-B chunk per level
 _PRETOUCH_BYTES = 8 << 20
 _STREAM_BYTES = 256 << 20  # total input bytes from which a single-GPU NumPy call is streamed in slices

@@ -25,7 +25,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--levels", type=int, default=137)
     ap.add_argument("--chunk", type=int, default=8)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"],
+                    help="f64: the fp64 walk (fp32 sign tests, fp64 residual on ambiguous steps) against the same walk with the fp64 "
+                         "residual at every step; the round-3 library is then compared in quanta (its fp64 exp2 differs by 1e-12)")
     a = ap.parse_args()
+    tag, npdt, isz = a.dtype, (np.float32 if a.dtype == "f32" else np.float64), (4 if a.dtype == "f32" else 8)
     new = load(_ffi.library_path())
     old_path = os.path.join(ROOT, "earthkit-meteo_amd", "variants", "r03", "libekm_thermo.so")
     old = load(old_path) if os.path.exists(old_path) else None
@@ -37,18 +41,20 @@ def main():
         chk(new.ekm_malloc(dev, nbytes, C.byref(p)))
         return p.value
 
-    t, q, p, o1, o2, o3 = (dmalloc(4 * nmax) for _ in range(6))
-    plev = dmalloc(4 * 137)
-    chk(new.ekm_synth_levels_f32(dev, None, plev, a.levels))
+    t, q, p, o1, o2, o3 = (dmalloc(isz * nmax) for _ in range(6))
+    plev = dmalloc(isz * 137)
+    chk(getattr(new, f'ekm_synth_levels_{tag}')(dev, None, plev, a.levels))
     from ekm_hip.vertical import hybrid_level_parameters
 
-    A, B = (x[137 - a.levels:].astype(np.float32) for x in hybrid_level_parameters(137))
-    sp = (101325.0 * (1.0 - 0.35 * np.random.default_rng(1).random(INNER) ** 3)).astype(np.float32)
+    A, B = (x[137 - a.levels:].astype(npdt) for x in hybrid_level_parameters(137))
+    sp = (101325.0 * (1.0 - 0.35 * np.random.default_rng(1).random(INNER) ** 3)).astype(npdt)
     dA, dB, dsp = dmalloc(A.nbytes), dmalloc(B.nbytes), dmalloc(sp.nbytes)
     for d, h in ((dA, A), (dB, B), (dsp, sp)):
         chk(new.ekm_h2d(dev, d, h.ctypes.data, h.nbytes, None))
     F = _ffi.Operand
-    host = [np.empty(nmax, np.float32) for _ in range(3)]
+    wb_new = getattr(new, f'ekm_wet_bulb_temperature_from_specific_humidity_{tag}')
+    wb_old = getattr(old, f'ekm_wet_bulb_temperature_from_specific_humidity_{tag}') if old is not None else None
+    host = [np.empty(nmax, npdt) for _ in range(3)]
     total = {m: [0, 0, 0] for m in ("field", "level", "hybrid")}  # points, default != all-exact, default != r03
     for lo in range(0, a.levels, a.chunk):
         hi = min(a.levels, lo + a.chunk)
@@ -56,33 +62,38 @@ def main():
         for mode in ("field", "level", "hybrid"):
             if mode == "hybrid":
                 ptmp = p
-                chk(new.ekm_pressure_on_hybrid_levels_f32(dev, None, dA + 4 * lo, dB + 4 * lo, dsp, INNER, hi - lo, None, None,
+                chk(getattr(new, f'ekm_pressure_on_hybrid_levels_{tag}')(dev, None, dA + isz * lo, dB + isz * lo, dsp, INNER, hi - lo, None, None,
                                                           int(lo == 0 and A[0] == 0 and B[0] == 0), float(np.log(2)), ptmp, None, None, None))
-                chk(new.ekm_synth_fill_given_p_f32(dev, None, t, q, ptmp, lo * INNER, n, 20260313))
+                chk(getattr(new, f'ekm_synth_fill_given_p_{tag}')(dev, None, t, q, ptmp, lo * INNER, n, 20260313))
                 nz = np.flatnonzero(B[lo:hi + 1] != 0.0)
                 nflat = int(max(0, (nz[0] if nz.size else hi + 1 - lo) - 1))
-                op_p = F(dsp, _ffi.HYBRID_FULL, nflat, hi - lo, INNER, dA + 4 * lo, dB + 4 * lo)
+                op_p = F(dsp, _ffi.HYBRID_FULL, nflat, hi - lo, INNER, dA + isz * lo, dB + isz * lo)
             else:
-                chk(new.ekm_synth_fill_f32(dev, None, t, q, p, lo * INNER, n, INNER, a.levels, 20260313))
-                op_p = F(p, _ffi.FIELD, 0, 0, 0) if mode == "field" else F(plev + 4 * lo, _ffi.LEVEL_MAJOR, 0, hi - lo, INNER)
+                chk(getattr(new, f'ekm_synth_fill_{tag}')(dev, None, t, q, p, lo * INNER, n, INNER, a.levels, 20260313))
+                op_p = F(p, _ffi.FIELD, 0, 0, 0) if mode == "field" else F(plev + isz * lo, _ffi.LEVEL_MAJOR, 0, hi - lo, INNER)
             ops = [C.byref(F(t, _ffi.FIELD, 0, 0, 0)), C.byref(F(q, _ffi.FIELD, 0, 0, 0)), C.byref(op_p)]
             chk(new.ekm_set_tuning_param(b"bisect_exact", 0))
-            chk(new.ekm_wet_bulb_temperature_from_specific_humidity_f32(dev, None, *ops, 0, 0, o1, n))
+            chk(wb_new(dev, None, *ops, 0, 0, o1, n))
             chk(new.ekm_set_tuning_param(b"bisect_exact", 1))
-            chk(new.ekm_wet_bulb_temperature_from_specific_humidity_f32(dev, None, *ops, 0, 0, o2, n))
+            chk(wb_new(dev, None, *ops, 0, 0, o2, n))
             chk(new.ekm_set_tuning_param(b"bisect_exact", 0))
             if old is not None:
-                chk(old.ekm_wet_bulb_temperature_from_specific_humidity_f32(dev, None, *ops, 0, 0, o3, n))
+                chk(wb_old(dev, None, *ops, 0, 0, o3, n))
             chk(new.ekm_sync(dev))
             for d, h in zip((o1, o2, o3), host):
-                chk(new.ekm_d2h(dev, h.ctypes.data, d, 4 * n, None))
+                chk(new.ekm_d2h(dev, h.ctypes.data, d, isz * n, None))
             chk(new.ekm_sync(dev))
-            u1, u2, u3 = (h[:n].view(np.uint32) for h in host)
+            u1, u2, u3 = (h[:n].view(np.uint32 if isz == 4 else np.uint64) for h in host)
             nan1, nan2, nan3 = (np.isnan(h[:n]) for h in host)
             total[mode][0] += n
             total[mode][1] += int((~((u1 == u2) | (nan1 & nan2))).sum())
             if old is not None:
-                total[mode][2] += int((~((u1 == u3) | (nan1 & nan3))).sum())
+                if isz == 4:
+                    total[mode][2] += int((~((u1 == u3) | (nan1 & nan3))).sum())
+                else:  # the round-3 fp64 primitives differ by ~1e-12: a sign can flip only where its residual is that small
+                    with np.errstate(all="ignore"):
+                        far = np.abs(host[0][:n] - host[2][:n]) > 2.0001 * 120.0 / 4096.0
+                    total[mode][2] += int((far | (nan1 != nan3)).sum())
         print(f"levels {lo}..{hi - 1}: " + ", ".join(f"{m} {v[1]}/{v[2]}" for m, v in total.items()), flush=True)
     for m, (n, d2, d3) in total.items():
         print(f"{m:6s}: {n} points; tree walk vs the same walk with the exact residual at every step: {d2} differ; "
