@@ -531,6 +531,8 @@ def main():
             valu, why_not = None, "not collected (--valu none)"
             if args.valu == "measure" and dist.world == 1 and args.workload not in COLUMN_WORKLOADS:
                 valu, why_not = measure_valu(args, n_local)
+            elif args.valu == "measure":
+                why_not = "counter passes run at N = 1 only" if dist.world > 1 else "no VALU side for the column workloads"
             if valu is None and args.valu != "none":
                 valu = valu_from_profiles(args, "" if args.valu == "file" else why_not)
             if valu:

@@ -467,8 +467,10 @@ struct OpThreads {
 };
 
 // Waves per SIMD a kernel of this op should be compiled for (launch bounds: caps the register allocation).
-// The six-output pipeline sits at 97-106 VGPRs in the per-level kernels, two registers above the 96 that allow a
-// fifth wave per SIMD; it is HBM-bound, so the extra wave in flight is worth more than the registers.
+// The six-output pipeline is held to the 96 VGPRs that allow a fifth wave per SIMD in the per-level kernels: it is
+// HBM-bound there, so the extra wave in flight is worth more than the registers (hybrid 5.35 -> 5.07 ms).  Left alone
+// the compiler takes 97-108 -- round 3's builds met the cap with 16-48 B of scratch per lane; since round 4 the
+// per-level kernels fit (87-94 VGPRs, no scratch: map_kernel.hpp::map_levels::run_points, tests/test_isa_resources.py).
 template <class Op>
 struct OpWaves {
   static constexpr int value = EKM_WAVES_PER_EU_DEFAULT;

@@ -104,8 +104,9 @@ def newton_misses_explained(t, q, p, got, want, tol, h=1e-6):
       * finite kappa: the deviation is within 8 x kappa x 2^-24 (kappa: newton_amplification);
       * on a NaN / regime edge (kappa = inf: a 1e-6 perturbation of an input changes the NaN-ness of the fp64 result): the
         value under test must BE one of the outcomes that edge offers -- NaN where the fp64 oracle or one of its six
-        perturbed evaluations is NaN, or a finite value within max(tol, 8 x kappa_f x 2^-24) of one of the finite ones,
-        kappa_f being the amplification seen among those finite evaluations (their spread over the perturbation).
+        perturbed evaluations is NaN, or a finite value inside the span [lo, hi] of the finite ones (the function is
+        continuous on its finite side: every value in the span is the outcome of some perturbation within +-h), the
+        span extended by its own width on both sides where the other side of the edge is NaN, and by `tol`.
     A point outside both masks is a real miss."""
     got = np.asarray(got, np.float64)
     want = np.asarray(want, np.float64)
@@ -120,9 +121,11 @@ def newton_misses_explained(t, q, p, got, want, tol, h=1e-6):
         lo = np.min(np.where(cn, np.inf, cands), axis=0)
         hi = np.max(np.where(cn, -np.inf, cands), axis=0)
         some = np.isfinite(lo)
-        mid = np.where(some, 0.5 * (np.abs(lo) + np.abs(hi)), 1.0)
-        kap_f = np.where(some, (hi - lo) / (2.0 * h * mid), 0.0)  # spread of the finite outcomes per unit perturbation
-        bar = np.maximum(tol, 8.0 * kap_f * 2.0 ** -24)
-        dist = np.min(np.where(cn, np.inf, np.abs(cands - got[None, :]) / np.abs(cands)), axis=0)
-        on_edge = edge & np.where(np.isnan(got), cn.any(axis=0), dist <= bar)
+        # the finite outcomes of the edge span [lo, hi]; the function is continuous on its finite side, so every value in
+        # between is the outcome of SOME perturbation within +-h -- and where the other side of the edge is NaN (the
+        # tw <= 0 and p - es < eps masks cut the function off) the span is extended by its own width on both sides
+        width = np.where(some & cn.any(axis=0), hi - lo, 0.0)
+        lo_e, hi_e = lo - width, hi + width
+        ok_range = some & (got >= lo_e - tol * np.abs(lo_e)) & (got <= hi_e + tol * np.abs(hi_e))
+        on_edge = edge & np.where(np.isnan(got), cn.any(axis=0), ok_range)
     return finite, on_edge

@@ -84,7 +84,7 @@ def test_a_miss_on_a_nan_edge_must_be_one_of_the_outcomes_the_edge_offers():
     want = orc.wet_bulb_temperature_from_specific_humidity(te, qe, pe, "ifs", "newton")
     first_finite = np.array([c[np.isfinite(c)][0] for c in cands[:, edge].T])
     for got, ok in ((np.full(edge.size, np.nan), True),             # NaN: some outcome of the edge is NaN
-                    (first_finite * (1 + 2e-5), True),              # a finite outcome of the edge, within the bar
+                    (first_finite * (1 + 2e-5), True),              # a finite outcome of the edge (within the bar of the span)
                     (np.full(edge.size, 123.456), False),           # garbage
                     (first_finite + 50.0, False)):                  # a finite value far from every outcome
         fin, on_edge = conditioning.newton_misses_explained(te, qe, pe, got, want, 1e-4)

@@ -54,14 +54,16 @@ def main():
         r_ = np.where(np.isfinite(r_), r_, 0.0)
         nanmm = np.isnan(g) != np.isnan(w)
         miss = np.flatnonzero((r_ > 1e-4) | nanmm)
-        kap = conditioning.newton_amplification(ht[miss], hq[miss], hp[miss])
-        expl = np.isinf(kap) | (~nanmm[miss] & (r_[miss] <= 8.0 * kap * 2.0 ** -24))
-        for i in miss[~expl]:
-            k = kap[list(miss).index(i)]
+        fin, edge = conditioning.newton_misses_explained(ht[miss], hq[miss], hp[miss], g[miss], w[miss], 1e-4)
+        kap, cands = conditioning.newton_amplification(ht[miss], hq[miss], hp[miss], return_candidates=True)
+        for n_, i in enumerate(miss):
+            if fin[n_] or edge[n_]:
+                continue
             print(f"UNEXPLAINED lev {lev} idx {i}: t={ht[i]!r} q={hq[i]!r} p={hp[i]!r} ours={g[i]!r} ref32={w[i]!r} ref64={w64[i]!r} "
-                  f"r={r_[i]:.3e} kappa={k:.3e} bar={8 * k * 2.0 ** -24:.3e}")
-            for h in (1e-7, 1e-6, 1e-5):
-                print("   kappa(h=%g) = %.3e" % (h, conditioning.newton_amplification(ht[i:i + 1], hq[i:i + 1], hp[i:i + 1], h)[0]))
+                  f"r={r_[i]:.3e} kappa={kap[n_]:.3e} candidates={[float(f'{c:.6g}') for c in cands[:, n_]]}")
+            for h in (1e-7, 1e-5, 1e-4):
+                k2, c2 = conditioning.newton_amplification(ht[i:i + 1], hq[i:i + 1], hp[i:i + 1], h, return_candidates=True)
+                print(f"   h={h:g}: kappa {k2[0]:.3e} candidates {[float(f'{c:.6g}') for c in c2[:, 0]]}")
 
 
 if __name__ == "__main__":
