@@ -636,6 +636,18 @@ def test_level_vector_shapes_pick_the_right_kernel(ek, orc, nlev, inner):
             assert x.shape == t.shape and np.array_equal(x, y, equal_nan=True), (func, nlev, inner)
     want = orc.potential_temperature(t, pl)
     assert_parity(ek.thermo.potential_temperature(t, pl), want, "f32", f"theta level vector {nlev}x{inner}")
+    # the reference's DEFAULT wet-bulb (bisection): the tree-walk kernels run 512-thread workgroups with their own tile
+    # size, in fp32 and (fp32 sign tests, fp64 residual) in fp64 -- same dispatch boundaries, same bits as the field path;
+    # and the vector along the trailing axis goes through map_bcast
+    for dt in (np.float32, np.float64):
+        a = ek.thermo.wet_bulb_temperature_from_specific_humidity(t.astype(dt), q.astype(dt), pl.astype(dt))
+        b = ek.thermo.wet_bulb_temperature_from_specific_humidity(t.astype(dt), q.astype(dt), pf.astype(dt))
+        assert a.dtype == dt and a.shape == t.shape and np.array_equal(a, b, equal_nan=True), ("bisect", dt, nlev, inner)
+    if nlev >= 4 and nlev <= 8:
+        tt, qt = np.ascontiguousarray(t.T), np.ascontiguousarray(q.T)   # [inner, nlev]: p varies along the LAST axis
+        a = ek.thermo.wet_bulb_temperature_from_specific_humidity(tt, qt, pl[:, 0])
+        full = ek.thermo.wet_bulb_temperature_from_specific_humidity(tt, qt, np.ascontiguousarray(pf.T))
+        assert np.array_equal(a, full, equal_nan=True), ("bisect level-minor", nlev, inner)
 
 
 def test_input_layouts_the_reference_accepts(ek, orc):
