@@ -16,6 +16,7 @@ run full            full:field:f32:137
 run p3              p3:field:f32:137            --workload p3
 run wetbulb         wetbulb:field:f32:137       --workload wetbulb
 run bisect          wetbulb_bisect:field:f32:137 --workload wetbulb_bisect
+run bisect_f64      wetbulb_bisect:field:f64:137 --workload wetbulb_bisect --dtype f64
 run bisect_bolton35 wetbulb_bisect_bolton35:field:f32:137 --workload wetbulb_bisect_bolton35
 run full_level      full:level:f32:137          --pmode level
 run full_hybrid     full:hybrid:f32:137         --pmode hybrid
