@@ -172,7 +172,6 @@ __device__ __forceinline__ void apply_points(const T (&x)[V][Op::NIN], T (&y)[V]
         fin = gap < fin ? gap : fin;
       }
     }
-#ifndef EKM_CENSUS_FAST_ONLY  // (ISA census aid: the first pass alone)
     const bool redo = fin == 0u || (switches & 1) != 0;  // f64_plain (tuning parameter, wave-uniform): every lane takes the plain pass
     if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
       if (redo) {
@@ -196,7 +195,6 @@ __device__ __forceinline__ void apply_points(const T (&x)[V][Op::NIN], T (&y)[V]
         }
       }
     }
-#endif
   } else {
 #pragma unroll
     for (int j = 0; j < V; ++j) op_apply<Op, T>(x[j], y[j], rp, tab);
@@ -281,11 +279,7 @@ __global__ __launch_bounds__((OpThreads<Op, T>::value), (OpThreads<Op, T>::field
   }
   // ragged tail: n % V single elements, done by the first lanes of workgroup 0
   const unsigned long long e = nvec * V + (unsigned long long)blockIdx.x * NT + threadIdx.x;
-#ifdef EKM_CENSUS_FAST_ONLY
-  if (false) {
-#else
   if (e < a.n) {
-#endif
     T x[NIN], y[NOUT];
 #pragma unroll
     for (int i = 0; i < NIN; ++i) x[i] = a.in[i][e];

@@ -244,11 +244,7 @@ struct BisectIfsTable {
   // behind it, the SAME fp32 tree for the sign tests (80 KiB).
   template <class T>
   static constexpr int count() {
-#ifdef EKM_HEAP_FAKE32K
-    return sizeof(T) == 4 ? 2 * kHeapNodes : kBisectLattice * BisectEntry<EPT_IFS, T>::width;
-#else
     return sizeof(T) == 4 ? 3 * kHeapNodes : kBisectLattice * BisectEntry<EPT_IFS, T>::width + 3 * kHeapNodes / 2;
-#endif
   }
   template <class T>
   EKM_HD static void fill(T* __restrict__ tab, int tid, int nthreads) {

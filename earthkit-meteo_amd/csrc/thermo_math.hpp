@@ -899,11 +899,7 @@ EKM_HD void bisect_heap_fill(float* __restrict__ tab, int i) {
   }
   tab[2 * i] = es;
   tab[2 * i + 1] = a;
-#ifndef EKM_HEAP_FAKE32K
   tab[2 * kHeapNodes + i] = L;
-#else
-  (void)L;
-#endif
 }
 
 // heap child of `node` by the sign of the residual: 2*node + (r > 0) -- one compare and one add-with-carry
@@ -933,11 +929,7 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
     tfix[j] = 0.0f;
   }
   const char* __restrict__ pairs = reinterpret_cast<const char*>(tab);
-#ifdef EKM_HEAP_FAKE32K  // timing experiment only (WRONG results): the logarithms read from inside the pair table, 32 KiB of LDS
-  const char* __restrict__ logs = pairs;
-#else
   const char* __restrict__ logs = pairs + 8 * kHeapNodes;
-#endif
 #pragma unroll
   for (int d = 0; d < 12; ++d) {
     float es[V], a[V], w[V], D[V];
