@@ -195,89 +195,52 @@ struct OpTable {
   }
 };
 
-// Bisection (the reference's DEFAULT t_method): the saturated parcel on the 4096-point search lattice
-// (thermo_math.hpp::BisectEntry: fp32 pairs (es_m, a_m), fp64 es_m alone; 32 KiB either way).
+// Bisection (the reference's DEFAULT t_method).  fp32 walks the search tree in heap order ((es, a) pairs + log2 t, 48 KiB;
+// thermo_math.hpp::t_on_ma_bisect_heap), all three theta_e methods.  fp64: the IFS method walks the same fp32 tree for
+// its sign tests with the lattice table of es in double behind it (80 KiB; t_on_ma_bisect_heap64); the Bolton methods
+// keep the stepwise search on their lattice table (t_on_ma_bisect_tab).  An op supplies `prep`: the quantity the search
+// inverts -- for ifs te = theta_e*(p/p0)^kappa, for the Bolton methods theta_e itself --, its logarithm
+// lte = log2(./273.16) (LOG), the pressure and, for bolton35, kl = kappa*log2(p/p0).
 template <int METHOD>
 struct BisectTable {
   typedef BisectTable<METHOD> table_type;  // all ops of one theta_e method share one device-resident table
   static constexpr int elems = kBisectLattice;
-  static constexpr bool vectorized = false;
   template <class T>
   static constexpr int count() {
-    return kBisectLattice * BisectEntry<METHOD, T>::width;
-  }
-  template <class T>
-  EKM_HD static void fill(T* __restrict__ tab, int tid, int nthreads) {
-    for (int m = tid; m < kBisectLattice; m += nthreads) BisectEntry<METHOD, T>::fill(tab, m);
-  }
-};
-// bolton35 / bolton39: theta_e as the reference forms it, then the table search
-template <int M>
-struct OpTable<OpTOnMa<M, T_BISECT>> : BisectTable<M> {
-  template <class T>
-  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
-    y[0] = t_on_ma_bisect_tab<M>(x[0], x[1], tab);
-  }
-};
-template <int M>
-struct OpTable<OpWetBulbFromTd<M, T_BISECT>> : BisectTable<M> {
-  template <class T>
-  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
-    y[0] = t_on_ma_bisect_tab<M>(ept<M, false>(x[0], x[1], x[2]), x[2], tab);
-  }
-};
-template <int M>
-struct OpTable<OpWetBulbFromQ<M, T_BISECT>> : BisectTable<M> {
-  template <class T>
-  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
-    y[0] = t_on_ma_bisect_tab<M>(ept<M, true>(x[0], x[1], x[2]), x[2], tab);
-  }
-};
-
-// The IFS method: fp32 walks the search tree in heap order with (es, a) pairs + log2 t (thermo_math.hpp::
-// t_on_ma_bisect_heap, 48 KiB), fp64 keeps the lattice table of es.  An op supplies `prep`: te = theta_e*(p/p0)^kappa,
-// its logarithm lte = log2(te/273.16) (fp32 only: LOG) and the pressure, from its own kind of input.
-struct BisectIfsTable {
-  typedef BisectIfsTable table_type;
-  static constexpr int elems = kBisectLattice;
-  // fp32: the tree (4096 (es, a) pairs + 4096 log2 t: 48 KiB).  fp64: the lattice table of es in double (32 KiB) and,
-  // behind it, the SAME fp32 tree for the sign tests (80 KiB).
-  template <class T>
-  static constexpr int count() {
-    return sizeof(T) == 4 ? 3 * kHeapNodes : kBisectLattice * BisectEntry<EPT_IFS, T>::width + 3 * kHeapNodes / 2;
+    return sizeof(T) == 4 ? 3 * kHeapNodes
+                          : kBisectLattice * BisectEntry<METHOD, T>::width + (METHOD == EPT_IFS ? 3 * kHeapNodes / 2 : 0);
   }
   template <class T>
   EKM_HD static void fill(T* __restrict__ tab, int tid, int nthreads) {
     for (int m = tid; m < kBisectLattice; m += nthreads) {
       if constexpr (sizeof(T) == 4) {
-        bisect_heap_fill(tab, m);
+        bisect_heap_fill<METHOD>(tab, m);
       } else {
-        BisectEntry<EPT_IFS, T>::fill(tab, m);
-        bisect_heap_fill(reinterpret_cast<float*>(tab + kBisectLattice), m);
+        BisectEntry<METHOD, T>::fill(tab, m);
+        if (METHOD == EPT_IFS) bisect_heap_fill<EPT_IFS>(reinterpret_cast<float*>(tab + kBisectLattice), m);
       }
     }
   }
 };
-template <class Derived, int NIN_>
-struct BisectIfsOp : BisectIfsTable {
+template <class Derived, int NIN_, int METHOD>
+struct BisectOp : BisectTable<METHOD> {
   static constexpr bool vectorized = true;  // map_kernel.hpp::apply_points hands over the V points of a lane together
   template <class T, int V>
   EKM_HD static void apply_v(const T (&x)[V][NIN_], T (&y)[V][1], T, const T* __restrict__ tab, bool all_exact = false) {
+    T te[V], lte[V], p[V], kl[V], out[V];
+    constexpr bool kTree = sizeof(T) == 4 || METHOD == EPT_IFS;
+#pragma unroll
+    for (int j = 0; j < V; ++j) Derived::template prep<T, kTree>(x[j], te[j], lte[j], p[j], kl[j]);
     if constexpr (sizeof(T) == 4) {
-      T te[V], lte[V], p[V], out[V];
-#pragma unroll
-      for (int j = 0; j < V; ++j) Derived::template prep<T, true>(x[j], te[j], lte[j], p[j]);
-      t_on_ma_bisect_heap<V>(lte, te, p, tab, out, all_exact);
-#pragma unroll
-      for (int j = 0; j < V; ++j) y[j][0] = out[j];
-    } else {  // double / fd64: sign tests in fp32 on the tree behind the fp64 table, ambiguous steps in T
-      T te[V], lte[V], p[V], out[V];
-#pragma unroll
-      for (int j = 0; j < V; ++j) Derived::template prep<T, true>(x[j], te[j], lte[j], p[j]);
+      t_on_ma_bisect_heap<METHOD, V>(lte, te, p, kl, tab, out, all_exact);
+    } else if constexpr (METHOD == EPT_IFS) {  // double / fd64: sign tests in fp32 on the tree behind the fp64 table
       t_on_ma_bisect_heap64<T, V>(lte, te, p, reinterpret_cast<const float*>(tab + kBisectLattice), tab, out, all_exact);
+    } else {
 #pragma unroll
-      for (int j = 0; j < V; ++j) y[j][0] = out[j];
+      for (int j = 0; j < V; ++j) out[j] = t_on_ma_bisect_tab<METHOD>(te[j], p[j], tab);
     }
+#pragma unroll
+    for (int j = 0; j < V; ++j) y[j][0] = out[j];
   }
   template <class T>
   EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T rp, const T* __restrict__ tab) {
@@ -286,6 +249,39 @@ struct BisectIfsOp : BisectIfsTable {
     for (int i = 0; i < NIN_; ++i) xx[0][i] = x[i];
     apply_v<T, 1>(xx, yy, rp, tab);
     y[0] = yy[0][0];
+  }
+};
+// bolton35 / bolton39: theta_e as the reference forms it
+template <int M, class T, bool LOG>
+EKM_HD void bolton_terms(T e, T p, T& lte, T& kl) {
+  lte = LOG ? m_log2(e * T(1.0 / 273.16)) : T(0);
+  kl = (LOG && M == EPT_BOLTON35) ? T(k::kappa) * m_log2(p * T(1.0 / k::p0)) : T(0);
+}
+template <int M>
+struct OpTable<OpTOnMa<M, T_BISECT>> : BisectOp<OpTable<OpTOnMa<M, T_BISECT>>, 2, M> {
+  template <class T, bool LOG>
+  EKM_HD static void prep(const T* __restrict__ x, T& e, T& lte, T& p, T& kl) {
+    e = x[0];
+    p = x[1];
+    bolton_terms<M, T, LOG>(e, p, lte, kl);
+  }
+};
+template <int M>
+struct OpTable<OpWetBulbFromTd<M, T_BISECT>> : BisectOp<OpTable<OpWetBulbFromTd<M, T_BISECT>>, 3, M> {
+  template <class T, bool LOG>
+  EKM_HD static void prep(const T* __restrict__ x, T& e, T& lte, T& p, T& kl) {
+    e = ept<M, false>(x[0], x[1], x[2]);
+    p = x[2];
+    bolton_terms<M, T, LOG>(e, p, lte, kl);
+  }
+};
+template <int M>
+struct OpTable<OpWetBulbFromQ<M, T_BISECT>> : BisectOp<OpTable<OpWetBulbFromQ<M, T_BISECT>>, 3, M> {
+  template <class T, bool LOG>
+  EKM_HD static void prep(const T* __restrict__ x, T& e, T& lte, T& p, T& kl) {
+    e = ept<M, true>(x[0], x[1], x[2]);
+    p = x[2];
+    bolton_terms<M, T, LOG>(e, p, lte, kl);
   }
 };
 // te from theta_e and p: te = theta_e*(p/p0)^kappa (thermo.py:1109-1110)
@@ -303,26 +299,29 @@ EKM_HD void ifs_te_from_tq(T t, T q, T tl, T& te, T& lte) {
   lte = LOG ? m_log2(t * T(1.0 / 273.16)) + xe : T(0);
 }
 template <>
-struct OpTable<OpTOnMa<EPT_IFS, T_BISECT>> : BisectIfsOp<OpTable<OpTOnMa<EPT_IFS, T_BISECT>>, 2> {
+struct OpTable<OpTOnMa<EPT_IFS, T_BISECT>> : BisectOp<OpTable<OpTOnMa<EPT_IFS, T_BISECT>>, 2, EPT_IFS> {
   template <class T, bool LOG>
-  EKM_HD static void prep(const T* __restrict__ x, T& te, T& lte, T& p) {
+  EKM_HD static void prep(const T* __restrict__ x, T& te, T& lte, T& p, T& kl) {
+    kl = T(0);
     p = x[1];
     ifs_te_from_ept<T, LOG>(x[0], p, te, lte);
   }
 };
 template <>
-struct OpTable<OpWetBulbFromTd<EPT_IFS, T_BISECT>> : BisectIfsOp<OpTable<OpWetBulbFromTd<EPT_IFS, T_BISECT>>, 3> {
+struct OpTable<OpWetBulbFromTd<EPT_IFS, T_BISECT>> : BisectOp<OpTable<OpWetBulbFromTd<EPT_IFS, T_BISECT>>, 3, EPT_IFS> {
   template <class T, bool LOG>
-  EKM_HD static void prep(const T* __restrict__ x, T& te, T& lte, T& p) {
+  EKM_HD static void prep(const T* __restrict__ x, T& te, T& lte, T& p, T& kl) {
+    kl = T(0);
     const T t = x[0], td = x[1];
     p = x[2];
     ifs_te_from_tq<T, LOG>(t, q_from_e(es_water(td), p, T(k::eps_default)), lcl_t<LCL_DAVIES>(t, td), te, lte);
   }
 };
 template <>
-struct OpTable<OpWetBulbFromQ<EPT_IFS, T_BISECT>> : BisectIfsOp<OpTable<OpWetBulbFromQ<EPT_IFS, T_BISECT>>, 3> {
+struct OpTable<OpWetBulbFromQ<EPT_IFS, T_BISECT>> : BisectOp<OpTable<OpWetBulbFromQ<EPT_IFS, T_BISECT>>, 3, EPT_IFS> {
   template <class T, bool LOG>
-  EKM_HD static void prep(const T* __restrict__ x, T& te, T& lte, T& p) {
+  EKM_HD static void prep(const T* __restrict__ x, T& te, T& lte, T& p, T& kl) {
+    kl = T(0);
     // the search only needs te = theta_e*(p/p0)^kappa -- no log2 / exp2 of the pressure at all
     const T t = x[0], q = x[1];
     p = x[2];
@@ -339,32 +338,38 @@ EKM_HD T wbpt_from_ept(T e, Tie& tie) {
 EKM_OP_T2(OpWbptFromTd, METHOD, TM, 3, 1, y[0] = wbpt_from_ept<METHOD, TM>(ept<METHOD, false>(x[0], x[1], x[2]), tie);)
 EKM_OP_T2(OpWbptFromQ, METHOD, TM, 3, 1, y[0] = wbpt_from_ept<METHOD, TM>(ept<METHOD, true>(x[0], x[1], x[2]), tie);)
 template <int M>
-struct OpTable<OpWbptFromTd<M, T_BISECT>> : BisectTable<M> {
-  template <class T>
-  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
-    y[0] = t_on_ma_bisect_tab<M>(ept<M, false>(x[0], x[1], x[2]), T(k::p0), tab);
+struct OpTable<OpWbptFromTd<M, T_BISECT>> : BisectOp<OpTable<OpWbptFromTd<M, T_BISECT>>, 3, M> {
+  template <class T, bool LOG>
+  EKM_HD static void prep(const T* __restrict__ x, T& e, T& lte, T& p, T& kl) {
+    e = ept<M, false>(x[0], x[1], x[2]);
+    p = T(k::p0);
+    bolton_terms<M, T, LOG>(e, p, lte, kl);
   }
 };
 template <int M>
-struct OpTable<OpWbptFromQ<M, T_BISECT>> : BisectTable<M> {
-  template <class T>
-  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T, const T* __restrict__ tab) {
-    y[0] = t_on_ma_bisect_tab<M>(ept<M, true>(x[0], x[1], x[2]), T(k::p0), tab);
+struct OpTable<OpWbptFromQ<M, T_BISECT>> : BisectOp<OpTable<OpWbptFromQ<M, T_BISECT>>, 3, M> {
+  template <class T, bool LOG>
+  EKM_HD static void prep(const T* __restrict__ x, T& e, T& lte, T& p, T& kl) {
+    e = ept<M, true>(x[0], x[1], x[2]);
+    p = T(k::p0);
+    bolton_terms<M, T, LOG>(e, p, lte, kl);
   }
 };
 template <>
-struct OpTable<OpWbptFromTd<EPT_IFS, T_BISECT>> : BisectIfsOp<OpTable<OpWbptFromTd<EPT_IFS, T_BISECT>>, 3> {
+struct OpTable<OpWbptFromTd<EPT_IFS, T_BISECT>> : BisectOp<OpTable<OpWbptFromTd<EPT_IFS, T_BISECT>>, 3, EPT_IFS> {
   template <class T, bool LOG>
-  EKM_HD static void prep(const T* __restrict__ x, T& te, T& lte, T& p) {
+  EKM_HD static void prep(const T* __restrict__ x, T& te, T& lte, T& p, T& kl) {
+    kl = T(0);
     p = T(k::p0);  // (p/p0)^kappa = 1 at p0: te = theta_e
     te = ept<EPT_IFS, false>(x[0], x[1], x[2]);
     lte = LOG ? m_log2(te * T(1.0 / 273.16)) : T(0);
   }
 };
 template <>
-struct OpTable<OpWbptFromQ<EPT_IFS, T_BISECT>> : BisectIfsOp<OpTable<OpWbptFromQ<EPT_IFS, T_BISECT>>, 3> {
+struct OpTable<OpWbptFromQ<EPT_IFS, T_BISECT>> : BisectOp<OpTable<OpWbptFromQ<EPT_IFS, T_BISECT>>, 3, EPT_IFS> {
   template <class T, bool LOG>
-  EKM_HD static void prep(const T* __restrict__ x, T& te, T& lte, T& p) {
+  EKM_HD static void prep(const T* __restrict__ x, T& te, T& lte, T& p, T& kl) {
+    kl = T(0);
     p = T(k::p0);
     te = ept<EPT_IFS, true>(x[0], x[1], x[2]);
     lte = LOG ? m_log2(te * T(1.0 / 273.16)) : T(0);
@@ -389,7 +394,7 @@ static_assert(OpTable<OpTOnMa<EPT_IFS, T_BISECT>>::elems > 0 && OpTable<OpTOnMa<
                   OpTable<OpWbptFromQ<EPT_IFS, T_BISECT>>::elems > 0 && OpTable<OpWbptFromQ<EPT_BOLTON35, T_BISECT>>::elems > 0 &&
                   OpTable<OpWbptFromQ<EPT_BOLTON39, T_BISECT>>::elems > 0,
               "a bisection op lost its lookup table");
-static_assert(OpTable<OpWetBulbFromQ<EPT_IFS, T_BISECT>>::vectorized && !OpTable<OpWetBulbFromQ<EPT_BOLTON35, T_BISECT>>::vectorized &&
+static_assert(OpTable<OpWetBulbFromQ<EPT_IFS, T_BISECT>>::vectorized && OpTable<OpWetBulbFromQ<EPT_BOLTON35, T_BISECT>>::vectorized &&
                   OpTable<OpWetBulbFromQ<EPT_IFS, T_NEWTON>>::elems == 0,
               "table traits");
 

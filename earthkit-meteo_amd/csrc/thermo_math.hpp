@@ -887,6 +887,7 @@ constexpr double kHeapTau0 = 2.5e-6, kHeapTau1 = 1.2e-6;
 // lattice index of heap node i at depth d (2^d <= i < 2^(d+1)), d <= 11
 EKM_HD int bisect_heap_lattice(int i, int d) { return (2 * (i - (1 << d)) + 1) << (11 - d); }
 
+template <int METHOD = EPT_IFS>
 EKM_HD void bisect_heap_fill(float* __restrict__ tab, int i) {
   float es = 0.0f, a = 0.0f, L = 0.0f;
   if (i >= 1) {
@@ -894,7 +895,7 @@ EKM_HD void bisect_heap_fill(float* __restrict__ tab, int i) {
     while ((2 << d) <= i) ++d;
     const float t = bisect_lattice_t<float>(bisect_heap_lattice(i, d));
     es = es_mixed(t);
-    a = bisect_second<EPT_IFS>(es, 1.0f / t);  // IEEE division: once per device
+    a = bisect_second<METHOD>(es, 1.0f / t);  // IEEE division: once per device
     L = (float)m_log2(double(t) * (1.0 / 273.16));
   }
   tab[2 * i] = es;
@@ -913,8 +914,16 @@ EKM_HD unsigned bisect_heap_child(unsigned node, float r) {
 #endif
 }
 
-template <int V>
-EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], const float (&p)[V],
+// The Bolton methods walk the same tree with their own second table value (bisect_second) and their own form of the test,
+// each the reference's residual in logarithms, multiplied through by the positive denominators (v = p - es_m > 0 outside
+// the NaN mask; inside it the result is NaN whatever the walk does):
+//   bolton35  g = kl + ws*(a_m - 0.28*kl), ws = eps*es_m/v, kl = kappa*log2(p/p0)   (thermo.py:1215-1224)
+//             g > u  <=>  D = (kl - u)*v + eps*es_m*(a_m - 0.28*kl) > 0                        no transcendental
+//   bolton39  g = a_m*ws*(1 + 0.448*ws) + kappa*log2(v/p0)                           (thermo.py:1280-1295)
+//             g > u  <=>  D = a_m*eps*es_m*(v + 0.448*eps*es_m) + v^2*(kappa*log2(v/p0) - u) > 0   ONE log2 (of three)
+// with u = L_m - le, le = log2(theta_e/273.16) (`te` is theta_e itself for these methods; `kl` is read for bolton35 only).
+template <int METHOD, int V>
+EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], const float (&p)[V], const float (&kl)[V],
                                 const float* __restrict__ tab, float (&out)[V], bool all_exact = false) {
   // esmax: the largest es visited, kept as its bit pattern -- the table's es are finite and >= 0, so their bit patterns
   // order like the values and the running maximum is ONE v_max_u32 (v_max_f32 wants a canonicalising copy of a freshly
@@ -946,11 +955,27 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
       a[j] = tab[2 * node[j] + 1];
 #endif
       const float u = *reinterpret_cast<const float*>(logs + (node[j] << 2)) - lte[j];
-      w[j] = m_fma(float(k::eps - 1), es[j], p[j]);
-      D[j] = m_fnma(u, w[j], a[j]);
+      float scale;  // |a_m| resp. its counterpart: the part of the band that goes with the size of the exponent
+      if (METHOD == EPT_IFS) {
+        w[j] = m_fma(float(k::eps - 1), es[j], p[j]);
+        D[j] = m_fnma(u, w[j], a[j]);
+        scale = a[j];
+      } else if (METHOD == EPT_BOLTON35) {
+        w[j] = p[j] - es[j];
+        scale = (float(k::eps) * es[j]) * m_fnma(0.28f, kl[j], a[j]);
+        D[j] = m_fma(kl[j] - u, w[j], scale);
+      } else {
+        w[j] = p[j] - es[j];
+        const float ees = float(k::eps) * es[j];
+        scale = (a[j] * ees) * m_fma(0.448f, ees, w[j]);
+        const float v2 = w[j] * w[j];
+        D[j] = m_fma(v2, m_fms(float(k::kappa), m_log2(w[j] * float(1.0 / k::p0)), u), scale);
+        thr0[j] = float(2.0 * kHeapTau0) * v2;  // the band in units of v^2 here (log2 of a small v adds its own rounding)
+      }
       const unsigned eb = __builtin_bit_cast(unsigned, es[j]);
       esmax[j] = esmax[j] > eb ? esmax[j] : eb;
-      amb[j] = !(__builtin_fabsf(D[j]) > m_fma(__builtin_fabsf(a[j]), float(kHeapTau1), thr0[j])) || all_exact;  // NaN: ambiguous
+      amb[j] = !(__builtin_fabsf(D[j]) > m_fma(__builtin_fabsf(scale), float(METHOD == EPT_IFS ? kHeapTau1 : 2.0 * kHeapTau1), thr0[j])) ||
+               all_exact;  // NaN: ambiguous
       any = any || amb[j];
     }
     if (EKM_ANY(any)) {  // the reference's own residual for the lanes that need it
@@ -958,7 +983,17 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
       for (int j = 0; j < V; ++j) {
         if (amb[j]) {
           const float tm = bisect_lattice_t<float>(bisect_heap_lattice((int)node[j], d));
-          const float r = m_fms(te[j], m_exp2(a[j] * m_rcp(w[j])), tm);
+          float g;  // the step of t_on_ma_bisect_tab, operation for operation
+          if (METHOD == EPT_IFS) {
+            g = a[j] * m_rcp(w[j]);
+          } else {
+            const float ws = float(k::eps) * es[j] * m_rcp(w[j]);
+            if (METHOD == EPT_BOLTON35)
+              g = m_fma(ws, m_fnma(0.28f, kl[j], a[j]), kl[j]);
+            else
+              g = m_fma(a[j] * ws, m_fma(0.448f, ws, 1.0f), float(k::kappa) * m_log2(w[j] * float(1.0 / k::p0)));
+          }
+          const float r = m_fms(te[j], m_exp2(g), tm);
           D[j] = r;
           if (!(r < 0.0f || r > 0.0f) && tfix[j] == 0.0f) {  // zero: the reference stays on this point; NaN: it turns NaN
             tfix[j] = r == 0.0f ? tm : r;  // (lattice temperatures are >= 133 K: never the "none" value)

@@ -28,7 +28,9 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"],
                     help="f64: the fp64 walk (fp32 sign tests, fp64 residual on ambiguous steps) against the same walk with the fp64 "
                          "residual at every step; the round-3 library is then compared in quanta (its fp64 exp2 differs by 1e-12)")
+    ap.add_argument("--method", default="ifs", choices=["ifs", "bolton35", "bolton39"])
     a = ap.parse_args()
+    meth = {"ifs": 0, "bolton35": 1, "bolton39": 2}[a.method]
     tag, npdt, isz = a.dtype, (np.float32 if a.dtype == "f32" else np.float64), (4 if a.dtype == "f32" else 8)
     new = load(_ffi.library_path())
     old_path = os.path.join(ROOT, "earthkit-meteo_amd", "variants", "r03", "libekm_thermo.so")
@@ -73,12 +75,12 @@ def main():
                 op_p = F(p, _ffi.FIELD, 0, 0, 0) if mode == "field" else F(plev + isz * lo, _ffi.LEVEL_MAJOR, 0, hi - lo, INNER)
             ops = [C.byref(F(t, _ffi.FIELD, 0, 0, 0)), C.byref(F(q, _ffi.FIELD, 0, 0, 0)), C.byref(op_p)]
             chk(new.ekm_set_tuning_param(b"bisect_exact", 0))
-            chk(wb_new(dev, None, *ops, 0, 0, o1, n))
+            chk(wb_new(dev, None, *ops, meth, 0, o1, n))
             chk(new.ekm_set_tuning_param(b"bisect_exact", 1))
-            chk(wb_new(dev, None, *ops, 0, 0, o2, n))
+            chk(wb_new(dev, None, *ops, meth, 0, o2, n))
             chk(new.ekm_set_tuning_param(b"bisect_exact", 0))
             if old is not None:
-                chk(wb_old(dev, None, *ops, 0, 0, o3, n))
+                chk(wb_old(dev, None, *ops, meth, 0, o3, n))
             chk(new.ekm_sync(dev))
             for d, h in zip((o1, o2, o3), host):
                 chk(new.ekm_d2h(dev, h.ctypes.data, d, isz * n, None))
