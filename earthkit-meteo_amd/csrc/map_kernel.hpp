@@ -146,7 +146,7 @@ __device__ __forceinline__ void apply_points(const T (&x)[V][Op::NIN], T (&y)[V]
       }
     }
   } else if constexpr (sizeof(T) == 4 && OpTable<Op>::elems > 0 && OpTable<Op>::vectorized) {
-    // the IFS bisection walks its search tree step by step for all V points together (one wave-uniform branch per step)
+    // the bisection walks its search tree step by step for all V points together (one wave-uniform branch per step)
     OpTable<Op>::template apply_v<T, V>(x, y, rp, tab, (switches & 2) != 0);
   } else if constexpr (sizeof(T) == 8 && EKM_F64_TWO_PASS) {
     // fp64: first pass in fdouble (thermo_math.hpp: primitives without special-operand fix-ups, which poison to NaN
