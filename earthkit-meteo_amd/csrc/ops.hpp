@@ -195,10 +195,9 @@ struct OpTable {
   }
 };
 
-// Bisection (the reference's DEFAULT t_method).  fp32 walks the search tree in heap order ((es, a) pairs + log2 t, 48 KiB;
-// thermo_math.hpp::t_on_ma_bisect_heap), all three theta_e methods.  fp64: the IFS method walks the same fp32 tree for
-// its sign tests with the lattice table of es in double behind it (80 KiB; t_on_ma_bisect_heap64); the Bolton methods
-// keep the stepwise search on their lattice table (t_on_ma_bisect_tab).  An op supplies `prep`: the quantity the search
+// Bisection (the reference's DEFAULT t_method), all three theta_e methods.  fp32 walks the search tree in heap order ((es,
+// a) pairs + log2 t, 48 KiB; thermo_math.hpp::t_on_ma_bisect_heap); fp64 walks the same fp32 tree for its sign tests with
+// the lattice table of es in double behind it (80 KiB; t_on_ma_bisect_heap64).  An op supplies `prep`: the quantity the search
 // inverts -- for ifs te = theta_e*(p/p0)^kappa, for the Bolton methods theta_e itself --, its logarithm
 // lte = log2(./273.16) (LOG), the pressure and, for bolton35, kl = kappa*log2(p/p0).
 template <int METHOD>
@@ -207,8 +206,7 @@ struct BisectTable {
   static constexpr int elems = kBisectLattice;
   template <class T>
   static constexpr int count() {
-    return sizeof(T) == 4 ? 3 * kHeapNodes
-                          : kBisectLattice * BisectEntry<METHOD, T>::width + (METHOD == EPT_IFS ? 3 * kHeapNodes / 2 : 0);
+    return sizeof(T) == 4 ? 3 * kHeapNodes : kBisectLattice * BisectEntry<METHOD, T>::width + 3 * kHeapNodes / 2;
   }
   template <class T>
   EKM_HD static void fill(T* __restrict__ tab, int tid, int nthreads) {
@@ -217,7 +215,7 @@ struct BisectTable {
         bisect_heap_fill<METHOD>(tab, m);
       } else {
         BisectEntry<METHOD, T>::fill(tab, m);
-        if (METHOD == EPT_IFS) bisect_heap_fill<EPT_IFS>(reinterpret_cast<float*>(tab + kBisectLattice), m);
+        bisect_heap_fill<METHOD>(reinterpret_cast<float*>(tab + kBisectLattice), m);
       }
     }
   }
@@ -228,17 +226,12 @@ struct BisectOp : BisectTable<METHOD> {
   template <class T, int V>
   EKM_HD static void apply_v(const T (&x)[V][NIN_], T (&y)[V][1], T, const T* __restrict__ tab, bool all_exact = false) {
     T te[V], lte[V], p[V], kl[V], out[V];
-    constexpr bool kTree = sizeof(T) == 4 || METHOD == EPT_IFS;
 #pragma unroll
-    for (int j = 0; j < V; ++j) Derived::template prep<T, kTree>(x[j], te[j], lte[j], p[j], kl[j]);
-    if constexpr (sizeof(T) == 4) {
+    for (int j = 0; j < V; ++j) Derived::template prep<T, true>(x[j], te[j], lte[j], p[j], kl[j]);
+    if constexpr (sizeof(T) == 4)
       t_on_ma_bisect_heap<METHOD, V>(lte, te, p, kl, tab, out, all_exact);
-    } else if constexpr (METHOD == EPT_IFS) {  // double / fd64: sign tests in fp32 on the tree behind the fp64 table
-      t_on_ma_bisect_heap64<T, V>(lte, te, p, reinterpret_cast<const float*>(tab + kBisectLattice), tab, out, all_exact);
-    } else {
-#pragma unroll
-      for (int j = 0; j < V; ++j) out[j] = t_on_ma_bisect_tab<METHOD>(te[j], p[j], tab);
-    }
+    else  // double / fd64: sign tests in fp32 on the tree behind the fp64 lattice table, ambiguous steps in T
+      t_on_ma_bisect_heap64<METHOD, T, V>(lte, te, p, kl, reinterpret_cast<const float*>(tab + kBisectLattice), tab, out, all_exact);
 #pragma unroll
     for (int j = 0; j < V; ++j) y[j][0] = out[j];
   }

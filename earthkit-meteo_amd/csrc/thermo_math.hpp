@@ -922,6 +922,31 @@ EKM_HD unsigned bisect_heap_child(unsigned node, float r) {
 //   bolton39  g = a_m*ws*(1 + 0.448*ws) + kappa*log2(v/p0)                           (thermo.py:1280-1295)
 //             g > u  <=>  D = a_m*eps*es_m*(v + 0.448*eps*es_m) + v^2*(kappa*log2(v/p0) - u) > 0   ONE log2 (of three)
 // with u = L_m - le, le = log2(theta_e/273.16) (`te` is theta_e itself for these methods; `kl` is read for bolton35 only).
+// D of one node (fp32): positive <=> the residual is positive, unless |D| <= the band (then `amb`).  w = the positive
+// denominator the exact step divides by (ifs: p + (eps-1)*es; Bolton: p - es); thr0 = the part of the band that goes with p.
+template <int METHOD>
+EKM_HD float bisect_fast_test(float es, float a, float u, float p, float kl, float& w, float thr0, bool& amb) {
+  float D, scale;  // scale: |a_m| resp. its counterpart -- the part of the band that goes with the size of the exponent
+  if (METHOD == EPT_IFS) {
+    w = m_fma(float(k::eps - 1), es, p);
+    D = m_fnma(u, w, a);
+    scale = a;
+  } else if (METHOD == EPT_BOLTON35) {
+    w = p - es;
+    scale = (float(k::eps) * es) * m_fnma(0.28f, kl, a);
+    D = m_fma(kl - u, w, scale);
+  } else {
+    w = p - es;
+    const float ees = float(k::eps) * es;
+    scale = (a * ees) * m_fma(0.448f, ees, w);
+    const float v2 = w * w;
+    D = m_fma(v2, m_fms(float(k::kappa), m_log2(w * float(1.0 / k::p0)), u), scale);
+    thr0 = float(2.0 * kHeapTau0) * v2;  // the band in units of v^2 here (log2 of a small v adds its own rounding)
+  }
+  amb = !(__builtin_fabsf(D) > m_fma(__builtin_fabsf(scale), float(METHOD == EPT_IFS ? kHeapTau1 : 2.0 * kHeapTau1), thr0));  // NaN: ambiguous
+  return D;
+}
+
 template <int METHOD, int V>
 EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], const float (&p)[V], const float (&kl)[V],
                                 const float* __restrict__ tab, float (&out)[V], bool all_exact = false) {
@@ -955,27 +980,10 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
       a[j] = tab[2 * node[j] + 1];
 #endif
       const float u = *reinterpret_cast<const float*>(logs + (node[j] << 2)) - lte[j];
-      float scale;  // |a_m| resp. its counterpart: the part of the band that goes with the size of the exponent
-      if (METHOD == EPT_IFS) {
-        w[j] = m_fma(float(k::eps - 1), es[j], p[j]);
-        D[j] = m_fnma(u, w[j], a[j]);
-        scale = a[j];
-      } else if (METHOD == EPT_BOLTON35) {
-        w[j] = p[j] - es[j];
-        scale = (float(k::eps) * es[j]) * m_fnma(0.28f, kl[j], a[j]);
-        D[j] = m_fma(kl[j] - u, w[j], scale);
-      } else {
-        w[j] = p[j] - es[j];
-        const float ees = float(k::eps) * es[j];
-        scale = (a[j] * ees) * m_fma(0.448f, ees, w[j]);
-        const float v2 = w[j] * w[j];
-        D[j] = m_fma(v2, m_fms(float(k::kappa), m_log2(w[j] * float(1.0 / k::p0)), u), scale);
-        thr0[j] = float(2.0 * kHeapTau0) * v2;  // the band in units of v^2 here (log2 of a small v adds its own rounding)
-      }
+      D[j] = bisect_fast_test<METHOD>(es[j], a[j], u, p[j], kl[j], w[j], thr0[j], amb[j]);
       const unsigned eb = __builtin_bit_cast(unsigned, es[j]);
       esmax[j] = esmax[j] > eb ? esmax[j] : eb;
-      amb[j] = !(__builtin_fabsf(D[j]) > m_fma(__builtin_fabsf(scale), float(METHOD == EPT_IFS ? kHeapTau1 : 2.0 * kHeapTau1), thr0[j])) ||
-               all_exact;  // NaN: ambiguous
+      amb[j] = amb[j] || all_exact;
       any = any || amb[j];
     }
     if (EKM_ANY(any)) {  // the reference's own residual for the lanes that need it
@@ -1028,12 +1036,13 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
 // nine orders below it), so outside it the fp32 sign IS the sign of the fp64 residual.
 // Largest es visited (the NaN rule): es grows with t, so it is es of the hottest node visited -- the first node the
 // walk left DOWNWARDS, or the deepest node if it never did -- read once at the end from the fp64 table.
-template <class T, int V>
-EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (&p)[V], const float* __restrict__ heap,
-                                  const T* __restrict__ es_tab, T (&out)[V], bool all_exact = false) {
+template <int METHOD, class T, int V>
+EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (&p)[V], const T (&kl)[V],
+                                  const float* __restrict__ heap, const T* __restrict__ es_tab, T (&out)[V],
+                                  bool all_exact = false) {
   unsigned node[V];
   int kfix[V];  // step at which the residual came out exactly zero / NaN (the reference then stays / turns NaN); -1 = never
-  float ltef[V], pf[V], thr0[V];
+  float ltef[V], pf[V], klf[V], thr0[V];
   T tfix[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) {
@@ -1041,6 +1050,7 @@ EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (
     kfix[j] = -1;
     ltef[j] = (float)lte[j];
     pf[j] = (float)p[j];
+    klf[j] = (float)kl[j];
     thr0[j] = float(1.5 * kHeapTau0) * pf[j];
     tfix[j] = T(0.0);
   }
@@ -1060,9 +1070,9 @@ EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (
       const float es = heap[2 * node[j]], a = heap[2 * node[j] + 1];
 #endif
       const float u = *reinterpret_cast<const float*>(logs + (node[j] << 2)) - ltef[j];
-      const float w = m_fma(float(k::eps - 1), es, pf[j]);
-      D[j] = m_fnma(u, w, a);
-      amb[j] = !(__builtin_fabsf(D[j]) > m_fma(__builtin_fabsf(a), float(1.5 * kHeapTau1), thr0[j])) || all_exact;
+      float w;
+      D[j] = bisect_fast_test<METHOD>(es, a, u, pf[j], klf[j], w, thr0[j], amb[j]);  // (the band is wide enough for the
+      amb[j] = amb[j] || all_exact;                                                  //  inputs' rounding to float)
       any = any || amb[j];
     }
     if (EKM_ANY(any)) {
@@ -1071,9 +1081,20 @@ EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (
         if (amb[j]) {
           const int m = bisect_heap_lattice((int)node[j], d);
           const T tm = bisect_lattice_t<T>(m), es = es_tab[m];
-          const T v = m_fma(T(k::eps - 1), es, p[j]);
-          const T r1 = m_rcp(v * tm);  // 1/(v*t) gives both 1/v and 1/t (t_on_ma_bisect_tab)
-          const T g = bisect_second<EPT_IFS>(es, r1 * v) * (r1 * tm);
+          // the step of t_on_ma_bisect_tab in T, operation for operation: 1/(v*t) gives both 1/v and 1/t
+          const T v = METHOD == EPT_IFS ? m_fma(T(k::eps - 1), es, p[j]) : p[j] - es;
+          const T r1 = m_rcp(v * tm);
+          const T rv = r1 * tm, a = bisect_second<METHOD>(es, r1 * v);
+          T g;
+          if (METHOD == EPT_IFS) {
+            g = a * rv;
+          } else {
+            const T ws = T(k::eps) * es * rv;
+            if (METHOD == EPT_BOLTON35)
+              g = m_fma(ws, m_fnma(T(0.28), kl[j], a), kl[j]);
+            else
+              g = m_fma(a * ws, m_fma(T(0.448), ws, T(1)), T(k::kappa) * m_log2(v * T(1.0 / k::p0)));
+          }
           const T r = m_fms(te[j], m_exp2(g), tm);
           D[j] = r > T(0) ? 1.0f : -1.0f;
           if (!(r < T(0) || r > T(0)) && kfix[j] < 0) {
