@@ -231,6 +231,18 @@ __device__ __forceinline__ void load_op_table(T* __restrict__ lds) {
     __syncthreads();                                                           \
   }
 
+// The full-field tree-walk kernels (80 registers for six waves per SIMD) form their load and store addresses from a copy
+// of the element index the compiler cannot see through: otherwise it strength-reduces them into one running 64-bit
+// pointer per stream, carried round the tile loop and alive across the whole body, and paid for them with 12-88 B of
+// scratch memory per lane (bolton35 bisection 4.87 -> 4.55 ms without it).  Kernels with registers to spare keep the
+// running pointers: the six-output pipeline measured 2 % slower with late addresses, and so did the per-level tree
+// walks, which never spilled (profiles/r04_late_index.txt).
+template <class Op, class T>
+__device__ __forceinline__ unsigned long long late_index(unsigned long long i) {
+  if constexpr (OpThreads<Op, T>::tree) asm volatile("" : "+v"(i));
+  return i;
+}
+
 // ---- all operands are aligned full fields ----------------------------------
 // Workgroup b owns `tiles` consecutive tiles of 256 vectors (256 x 16 B = 4 KiB per
 // stream per tile) and exits: the dispatcher hands out workgroups in order, so at any
@@ -251,8 +263,9 @@ __global__ __launch_bounds__((OpThreads<Op, T>::value), (OpThreads<Op, T>::field
     for (int u = 0; u < UNROLL; ++u) {
       const unsigned long long v = v0 + u * NT;
       if (v < nvec) {
+        const unsigned long long vl = late_index<Op, T>(v);
 #pragma unroll
-        for (int i = 0; i < NIN; ++i) xin[u][i] = ld_stream<T>(a.in[i] + v * V);
+        for (int i = 0; i < NIN; ++i) xin[u][i] = ld_stream<T>(a.in[i] + vl * V);
       }
     }
 #pragma unroll
@@ -272,8 +285,9 @@ __global__ __launch_bounds__((OpThreads<Op, T>::value), (OpThreads<Op, T>::field
 #pragma unroll
           for (int o = 0; o < NOUT; ++o) yout[o][j] = y[j][o];
         }
+        const unsigned long long vs = late_index<Op, T>(v);
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) st_stream<T>(a.out[o] + v * V, yout[o]);
+        for (int o = 0; o < NOUT; ++o) st_stream<T>(a.out[o] + vs * V, yout[o]);
       }
     }
   }
@@ -847,7 +861,8 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
       // The level walk exists for one-in one-out ops only (kWalk): with more streams it measured slower (P3 3.01 -> 3.28 ms,
       // profiles/r02_sweep_hybrid.txt) and its carried registers pushed the six-output pipeline into scratch memory, so
       // for those ops the tuning parameter lev_per_wg has no effect (include/ekm_thermo.h says so).
-      constexpr bool kWalk = NIN - 1 + NOUT <= 2;
+      // Nor for a tree walk: the carried registers do not fit beside its state (20-60 B of scratch per lane for 1 %).
+      constexpr bool kWalk = NIN - 1 + NOUT <= 2 && !OpThreads<Op, T>::tree;
       unsigned lpw = 1u;
       if (pm == EKM_HYBRID_FULL && kWalk) lpw = tuning_lev_per_wg() > 0 ? (unsigned)tuning_lev_per_wg() : 4u;
       // shapes this kernel is not meant for go to map_bcast: rows longer than 32-bit columns, more level
@@ -924,10 +939,14 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
   } else if (a.aux0) {
     return set_error(EKM_ERR_ARG, "EKM_HYBRID_FULL needs full-field operands before it");
   } else if (!bc && aligned) {
-    if (unroll >= 2)
-      hipLaunchKernelGGL((map_fields<Op, T, 2>), dim3(grid), dim3(NT), 0, s, a, tiles);
-    else
-      hipLaunchKernelGGL((map_fields<Op, T, 1>), dim3(grid), dim3(NT), 0, s, a, tiles);
+    // (two tiles in flight per lane double the state of a tree walk: those kernels have no such instantiation)
+    if constexpr (!OpThreads<Op, T>::tree) {
+      if (unroll >= 2) {
+        hipLaunchKernelGGL((map_fields<Op, T, 2>), dim3(grid), dim3(NT), 0, s, a, tiles);
+        unroll = -1;
+      }
+    }
+    if (unroll >= 0) hipLaunchKernelGGL((map_fields<Op, T, 1>), dim3(grid), dim3(NT), 0, s, a, tiles);
   } else {
     const unsigned long long step = (unsigned long long)NT * V;  // elements per tile
     for (int i = 0; i < NIN; ++i) {

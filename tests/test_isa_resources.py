@@ -41,3 +41,64 @@ def test_the_benchmarked_pipeline_kernels_keep_five_waves_per_simd(kernels):
     assert len(want) == 4, want
     for k in want:
         assert kernels[k][0] <= 96, (k, kernels[k])
+
+
+# ---- every kernel of the BUILT library, from the code objects' own metadata (seconds, no compilation) ----------------
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+LIB = os.path.join(ROOT, "earthkit-meteo_amd", "ekm_hip", "lib", "libekm_thermo.so")
+
+
+@pytest.fixture(scope="module")
+def built_kernels(tmp_path_factory):
+    objdump, readelf = os.path.join(LLVM_BIN, "llvm-objdump"), os.path.join(LLVM_BIN, "llvm-readelf")
+    if not (os.path.exists(objdump) and os.path.exists(readelf) and os.path.exists(LIB)):
+        pytest.skip("llvm-objdump / llvm-readelf or the built library not available")
+    work = tmp_path_factory.mktemp("codeobj")
+    shutil.copy(LIB, work / "lib.so")
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=work, check=True, capture_output=True, timeout=300)
+    found = {}
+    for f in sorted(os.listdir(work)):
+        if "gfx950" not in f:
+            continue
+        notes = subprocess.run([readelf, "--notes", f], cwd=work, check=True, capture_output=True, text=True, timeout=300).stdout
+        for block in notes.split("\n  - .agpr_count:")[1:]:
+            get = lambda key: re.search(r"^    \." + key + r":\s*(\S+)", block, re.M).group(1)  # noqa: E731
+            found[get("name")] = {"vgpr": int(get("vgpr_count")), "scratch": int(get("private_segment_fixed_size")),
+                                  "lds": int(get("group_segment_fixed_size")), "threads": int(get("max_flat_workgroup_size"))}
+    assert len(found) > 1500, len(found)
+    return found
+
+
+# a tree walk's kernels: the bisection entry points (T_BISECT = 0: OpTOnMa<M, 0>, OpWetBulbFromTd/Q<M, 0>, OpWbptFromTd/Q<M, 0>)
+TREE = re.compile(r"(7OpTOnMa|15OpWetBulbFromTd|14OpWetBulbFromQ|12OpWbptFromTd|11OpWbptFromQ)ILi\dELi0EEE")
+
+
+def test_no_kernel_of_the_built_library_runs_out_of_registers(built_kernels):
+    """Scratch memory = registers spilled: nowhere, except 12 B per lane in two bolton35 tree-walk kernels, spilled once at
+    kernel entry (the lane's first element index, reloaded for the ragged tail), outside the tile loop."""
+    allowed = re.compile(r"map_fieldsINS_1[45]OpWetBulbFrom(Q|Td)ILi1ELi0EEEfLi1E")
+    bad = {k: v for k, v in built_kernels.items() if v["scratch"] > (12 if allowed.search(k) else 0)}
+    assert not bad, bad
+
+
+def test_tree_walk_kernels_keep_their_occupancy(built_kernels):
+    """512 threads around one copy of the tree: fp32 48 KiB and <= 80 registers (three workgroups = six waves per SIMD),
+    fp64 80 KiB and <= 128 registers (two workgroups = four waves per SIMD); no two-tile or level-walk instantiation."""
+    tree = {k: v for k, v in built_kernels.items() if TREE.search(k) and ("map_fields" in k or "map_levels" in k or "map_bcast" in k)}
+    assert len(tree) >= 2 * 15 * 8, len(tree)
+    for k, v in tree.items():
+        f64 = re.search(r"EEEd(Li|EE)", k) is not None
+        assert v["threads"] == 512, (k, v)
+        assert v["lds"] == ((80 if f64 else 48) << 10), (k, v)
+        if "map_bcast" not in k:
+            assert v["vgpr"] <= (128 if f64 else 80), (k, v)
+        assert not re.search(r"map_fields.*Li2EEEv", k), k                      # UNROLL = 2
+        assert not re.search(r"map_levels.*ELb[01]ELb1EEEv", k), k              # WALK
+
+
+def test_six_output_pipeline_kernels_of_the_built_library(built_kernels):
+    want = [k for k in built_kernels if "14OpPipelineFullEf" in k and ("map_fieldsINS_14OpPipelineFullEfLi1E" in k or
+                                                                        ("map_levels" in k and "ELb1ELb0E" in k))]
+    assert len(want) == 4, want
+    for k in want:
+        assert built_kernels[k]["vgpr"] <= 96 and built_kernels[k]["scratch"] == 0 and built_kernels[k]["lds"] == 0, (k, built_kernels[k])

@@ -197,19 +197,19 @@ EKM_API int ekm_event_elapsed_ms(int dev, void* start, void* stop, float* ms);
 
 /* ---- launch tuning (process-wide; defaults are the measured best) ---- */
 /* tiles_per_block: consecutive 4-KiB tiles (256 lanes x 16 B) one workgroup streams per field;
- * unroll: tiles in flight per lane per trip (1 or 2).  0 keeps a value. */
+ * unroll: tiles in flight per lane per trip (1 or 2; the bisection functions' tree-walk kernels always take 1).  0 keeps a value. */
 EKM_API int ekm_set_tuning(int tiles_per_block, int unroll);
 EKM_API int ekm_get_tuning(int* tiles_per_block, int* unroll);
 /* secondary parameters by name (defaults from the environment, in brackets):
  *   "hybrid_band_kb" [EKM_HYBRID_BAND_KB, 8192]  EKM_HYBRID_FULL: KiB of surface pressure per L2-resident band;
- *   "lev_per_wg"     [EKM_LEV_PER_WG, 0]         EKM_HYBRID_FULL, one-in one-out functions only (theta ...): consecutive levels one workgroup walks (0 = 4); no effect on functions with more streams;
+ *   "lev_per_wg"     [EKM_LEV_PER_WG, 0]         EKM_HYBRID_FULL, one-in one-out functions only (theta ...): consecutive levels one workgroup walks (0 = 4); no effect on functions with more streams or on the bisection functions;
  *   "table_tiles"    [EKM_TABLE_TILES, 0]        most tiles per workgroup for ops that keep an LDS table (bisection); 0 = by op (8 or 16);
  *   "geo_chunk_levels" [EKM_GEO_CHUNK_LEVELS, all] levels per launch of the geopotential column scan;
  *   "f64_plain"        [EKM_F64_PLAIN, 0]          1: the fp64 map kernels redo EVERY lane with the plain-double primitives
  *                      (IEEE special operands fixed up as libm does) instead of only the lanes whose fast first pass
  *                      produced a non-finite output; same results, for tests and A/B timing;
- *   "bisect_exact"     [EKM_BISECT_EXACT, 0]       1: the fp32 IFS bisection evaluates the reference's residual (rcp + exp2) at
- *                      EVERY step of its tree walk instead of only where the transcendental-free sign test is within
+ *   "bisect_exact"     [EKM_BISECT_EXACT, 0]       1: the bisection functions (every method, fp32 and fp64) evaluate the reference's residual (rcp + exp2) at
+ *                      EVERY step of their tree walk instead of only where the transcendental-free sign test is within
  *                      rounding of zero; same results, for tests and A/B timing. */
 EKM_API int ekm_set_tuning_param(const char* name, int value);
 /* The table-driven functions (wet-bulb / moist-adiabat inversion by bisection) read a lookup table that is computed on
