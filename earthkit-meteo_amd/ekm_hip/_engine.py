@@ -12,6 +12,7 @@ DeviceArrays; broadcast operands (a scalar, a level vector along the leading or
 trailing axes) are passed to the kernels as such instead of being materialised.
 """
 import ctypes as C
+import math
 import os
 import threading
 
@@ -75,8 +76,8 @@ def classify(shape, out_shape):
     Returns (mode, len, inner) with mode one of FIELD / SCALAR / LEVEL_MAJOR /
     LEVEL_MINOR, or None when the pattern needs materialising.
     """
-    size = int(np.prod(shape, dtype=np.int64))
-    n = int(np.prod(out_shape, dtype=np.int64))
+    size = int(math.prod(shape))
+    n = int(math.prod(out_shape))
     if size == 1 and n != 1:
         return _ffi.SCALAR, 0, 0
     s = _padded(shape, len(out_shape))
@@ -88,7 +89,7 @@ def classify(shape, out_shape):
         return None  # a 1 in the middle of the block: not a plain vector
     if lo == 0 or all(out_shape[i] == 1 for i in range(lo)):
         # varies along the leading axes only: value index = flat_index // inner
-        inner = int(np.prod(out_shape[hi + 1:], dtype=np.int64))
+        inner = int(math.prod(out_shape[hi + 1:]))
         if inner >= _MIN_VEC:
             return _ffi.LEVEL_MAJOR, size, inner
     if hi == len(out_shape) - 1:
@@ -130,7 +131,7 @@ class _Plan:
         self.shape = tuple(np.broadcast_shapes(*shapes))
         if self.hybrid and (self.shape != self.hybrid[0].shape or any(tuple(s) != self.shape for s in shapes[:-1])):
             raise ValueError(f"HybridPressure of shape {self.hybrid[0].shape} needs fields of exactly that shape")
-        self.n = int(np.prod(self.shape, dtype=np.int64))
+        self.n = int(math.prod(self.shape))
 
 
 _KDLCPU, _KDLROCM, _KDLROCMHOST = 1, 10, 11
@@ -363,9 +364,9 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
         out_dtype = cdtype = np.dtype(dtype)
     nout = len(OPS[name][1])
     spans = [h.ndim == len(shape) and h.shape[0] == shape[0] for h in host]
-    row_pts = int(np.prod(shape[1:], dtype=np.int64))
+    row_pts = int(math.prod(shape[1:]))
     # device bytes per leading-axis row: sliced inputs (a broadcast row still costs its own size) + outputs
-    row_bytes = (sum(int(np.prod(h.shape[1:], dtype=np.int64)) for h, sp in zip(host, spans) if sp) + nout * row_pts) * cdtype.itemsize
+    row_bytes = (sum(int(math.prod(h.shape[1:])) for h, sp in zip(host, spans) if sp) + nout * row_pts) * cdtype.itemsize
     blocks = [b for b in leading_axis_bounds(shape[0], len(devs)) if b[1] > b[0]]
     plans = []
     for dev, (lo, hi) in zip(devs, blocks):
@@ -380,7 +381,7 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
     # the downloads are then plain DMAs -- no page faults, no pin / unpin around every copy.  Beyond that (or when
     # pinned memory cannot be had) ordinary arrays, prefaulted slice by slice.
     outs, pinned_outs = None, False
-    if _PINNED_OUT and nout * int(np.prod(shape, dtype=np.int64)) * out_dtype.itemsize <= _PINNED_OUT_BYTES:
+    if _PINNED_OUT and nout * int(math.prod(shape)) * out_dtype.itemsize <= _PINNED_OUT_BYTES:
         from .device import pinned_empty
 
         outs = [pinned_empty(shape, out_dtype) for _ in range(nout)]

@@ -8,6 +8,7 @@ HBM time).  NumPy inputs are uploaded, computed on and downloaded per call.
 """
 import ctypes as C
 import itertools
+import math
 import os
 import threading
 import weakref
@@ -319,7 +320,7 @@ class DeviceArray:
             raise TypeError(f"DeviceArray supports float32/float64, not {dtype}")
         shape = (shape,) if np.isscalar(shape) else tuple(int(s) for s in shape)
         device = current_device() if device is None else device
-        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        nbytes = int(math.prod(shape)) * dtype.itemsize
         alloc = _Allocation(nbytes, device, capacity)
         return cls(alloc, alloc.ptr, shape, dtype, device)
 
@@ -335,7 +336,7 @@ class DeviceArray:
     # ---- properties ----
     @property
     def size(self):
-        return int(np.prod(self.shape, dtype=np.int64))
+        return int(math.prod(self.shape))
 
     @property
     def nbytes(self):
@@ -443,11 +444,11 @@ def _resolve_shape(shape, size):
     if shape.count(-1) > 1:
         raise ValueError("can only specify one unknown dimension")
     if -1 in shape:
-        known = int(np.prod([s for s in shape if s != -1], dtype=np.int64))
+        known = int(math.prod([s for s in shape if s != -1]))
         if known == 0 or size % known:
             raise ValueError(f"cannot reshape array of size {size} into shape {tuple(shape)}")
         shape[shape.index(-1)] = size // known
-    if int(np.prod(shape, dtype=np.int64)) != size:
+    if int(math.prod(shape)) != size:
         raise ValueError(f"cannot reshape array of size {size} into shape {tuple(shape)}")
     return tuple(shape)
 
@@ -528,12 +529,12 @@ def pinned_empty(shape, dtype=np.float32):
 
     dtype = np.dtype(dtype)
     shape = (shape,) if np.isscalar(shape) else tuple(int(s) for s in shape)
-    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    nbytes = int(math.prod(shape)) * dtype.itemsize
     ptr, b = _pinned.take(max(nbytes, 1))
     if ptr is None:
         return None
     buf = (C.c_char * max(nbytes, 1)).from_address(ptr)
-    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(math.prod(shape))).reshape(shape)
     # `buf` is the base object every view of `arr` keeps alive: when it goes, the block returns to the pool
     weakref.finalize(buf, _pinned.give, ptr, b)
     return arr

@@ -8,6 +8,7 @@ NumPy out; `DeviceArray` `sp` in -> DeviceArrays out (then `vertical_axis` must 
 materialised pressure field (ekm_hip.thermo functions accept it in place of `p`).
 """
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -107,7 +108,7 @@ def pressure_on_hybrid_levels(A, B, sp, levels=None, alpha_top="ifs", output="fu
         A, B, sel = _select_levels(A, B, levels)
     nfull = A.shape[0] - 1
     sp_shape = tuple(sp.shape)
-    npts = int(np.prod(sp_shape, dtype=np.int64))
+    npts = int(math.prod(sp_shape))
 
     # output rows: identity, or the requested levels in the requested order
     if sel is None:
@@ -223,7 +224,7 @@ def _chain(t, q, zs, A, B, sp, alpha_top, mode, vertical_axis):
     if nlev_t > nlev:
         raise ValueError(f"data have {nlev_t} levels, A/B have {nlev} levels")
     A, B = A[nlev - nlev_t:], B[nlev - nlev_t:]  # the bottom-most nlev_t layers (vertical.py:1191-1203)
-    npts = int(np.prod(shape[1:], dtype=np.int64))
+    npts = int(math.prod(shape[1:]))
     device = next((v.device for v in host.values() if isinstance(v, DeviceArray)), current_device())
 
     def dev(v):
@@ -278,7 +279,7 @@ def relative_geopotential_thickness_on_hybrid_levels_from_alpha_delta(t, q, alph
     if len(shape) == 0 or any(tuple(v.shape) != shape for v in host.values()):
         raise ValueError("t, q, alpha and delta must have the same shape [levels, ...]: "
                          + ", ".join(f"{k} {tuple(v.shape)}" for k, v in host.items()))
-    nlev, npts = shape[0], int(np.prod(shape[1:], dtype=np.int64))
+    nlev, npts = shape[0], int(math.prod(shape[1:]))
     device = next((v.device for v in host.values() if isinstance(v, DeviceArray)), current_device())
     stream = current_stream()
     d = {}
