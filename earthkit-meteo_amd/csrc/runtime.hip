@@ -429,6 +429,58 @@ int ekm_stream_wait_event(int dev, void* stream, void* event) {
   return EKM_OK;
 }
 
+// ---- HIP graphs: record the launches of a stream once, replay them with one call -----------------------------------
+// Every compute entry point only enqueues work on the caller's stream (no allocation, no host wait: ensure_op_table), so a
+// sequence of them between ekm_graph_begin and ekm_graph_end is recorded instead of run.  Relaxed capture mode: the caller
+// may allocate (ekm_malloc) while recording; copies from pageable host memory and waits cannot be recorded and fail.
+int ekm_graph_begin(int dev, void* stream) {
+  if (!stream) return set_error(EKM_ERR_ARG, "graph_begin: the default stream cannot be captured; pass a stream from ekm_stream_create");
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  EKM_HIP(hipStreamBeginCapture(static_cast<hipStream_t>(stream), hipStreamCaptureModeRelaxed));
+  return EKM_OK;
+}
+
+int ekm_graph_end(int dev, void* stream, void** graph_exec) {
+  if (graph_exec) *graph_exec = nullptr;
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  hipGraph_t g = nullptr;
+  hipError_t err = hipStreamEndCapture(static_cast<hipStream_t>(stream), &g);  // always ends the capture, valid or not
+  if (err != hipSuccess || !g) {
+    (void)hipGetLastError();
+    if (g) (void)hipGraphDestroy(g);
+    return set_error(EKM_ERR_HIP, "graph_end: the capture is invalid (%s): something between begin and end could not be recorded",
+                     hipGetErrorString(err));
+  }
+  if (!graph_exec) {  // capture abandoned by the caller
+    (void)hipGraphDestroy(g);
+    return EKM_OK;
+  }
+  hipGraphExec_t x = nullptr;
+  err = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (err != hipSuccess) return set_error(EKM_ERR_HIP, "graph_end: hipGraphInstantiate: %s", hipGetErrorString(err));
+  *graph_exec = x;
+  return EKM_OK;
+}
+
+int ekm_graph_launch(int dev, void* graph_exec, void* stream) {
+  if (!graph_exec) return set_error(EKM_ERR_ARG, "graph_launch: null graph");
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  EKM_HIP(hipGraphLaunch(static_cast<hipGraphExec_t>(graph_exec), static_cast<hipStream_t>(stream)));
+  return EKM_OK;
+}
+
+int ekm_graph_destroy(int dev, void* graph_exec) {
+  if (!graph_exec) return EKM_OK;
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  EKM_HIP(hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec)));
+  return EKM_OK;
+}
+
 int ekm_event_sync(int dev, void* event) {
   int rc = use_device(dev);
   if (rc != EKM_OK) return rc;

@@ -20,7 +20,7 @@ import numpy as np
 
 from . import _ffi
 from ._optable import OPS
-from .device import DeviceArray, current_device, current_stream
+from .device import DeviceArray, _capturing, current_device, current_stream
 from .vertical import HybridPressure
 
 _F32, _F64 = np.dtype(np.float32), np.dtype(np.float64)
@@ -156,6 +156,9 @@ def _adopt_foreign(args):
         if kind == _KDLROCM:
             from .dlpack import from_dlpack
 
+            if _capturing() is not None:
+                raise _ffi.EkmError("inside an ekm_hip.graph() block the operands must be ekm_hip DeviceArrays; take another "
+                                    "library's array over with ekm_hip.from_dlpack before the block")
             try:
                 out.append(from_dlpack(a))
             except ValueError:  # not C-contiguous: the producer's own compaction, then zero copy

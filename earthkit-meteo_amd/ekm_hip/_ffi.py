@@ -63,6 +63,8 @@ def _signatures():
         "ekm_event_record": ([i, vp, vp], i), "ekm_event_sync": ([i, vp], i),
         "ekm_stream_wait_event": ([i, vp, vp], i),
         "ekm_event_elapsed_ms": ([i, vp, vp, C.POINTER(C.c_float)], i),
+        "ekm_graph_begin": ([i, vp], i), "ekm_graph_end": ([i, vp, pvp], i),
+        "ekm_graph_launch": ([i, vp, vp], i), "ekm_graph_destroy": ([i, vp], i),
         "ekm_set_tuning": ([i, i], i), "ekm_set_tuning_param": ([C.c_char_p, i], i), "ekm_prepare_tables": ([i], i), "ekm_get_tuning": ([C.POINTER(i), C.POINTER(i)], i),
         "ekm_synth_fill_f32": ([i, vp, vp, vp, vp, u64, sz, u64, u32, u64], i),
         "ekm_synth_fill_f64": ([i, vp, vp, vp, vp, u64, sz, u64, u32, u64], i),

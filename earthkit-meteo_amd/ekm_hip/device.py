@@ -135,7 +135,21 @@ def order_streams(dev, first, then):
 
 
 def synchronize(dev=None):
+    _no_capture("synchronize()")
     _ffi.check(_ffi.lib().ekm_sync(current_device() if dev is None else dev))
+
+
+def _capturing():
+    """The `ekm_hip.graph()` block this thread is recording into, or None."""
+    return getattr(_tls, "capture", None)
+
+
+def _no_capture(what):
+    if _capturing() is not None:
+        raise _ffi.EkmError(f"{what} inside an ekm_hip.graph() block: the block RECORDS kernel launches, nothing runs in it, so "
+                            "host <-> device copies and waits have no place there -- move data with to_device / "
+                            "copy_from_host / to_host before or after the block (Python scalars and NumPy operands "
+                            "included: wrap them with ekm_hip.to_device first)")
 
 
 class _BlockCache:
@@ -256,7 +270,7 @@ class _Allocation:
     on it is ordered before the tail of `stream`, the list it is cached under.
     """
 
-    __slots__ = ("ptr", "base", "nbytes", "device", "stream", "bucket", "exported", "_lock", "__weakref__")
+    __slots__ = ("ptr", "base", "nbytes", "device", "stream", "bucket", "exported", "pins", "free_pending", "_lock", "__weakref__")
 
     def __init__(self, nbytes, device, capacity=0):
         self.device, self.nbytes, self.stream = device, nbytes, current_stream()
@@ -266,6 +280,7 @@ class _Allocation:
         # so the blocks are plain again.)
         self.bucket = _BlockCache.bucket(nbytes)
         self.exported = False  # handed to a DLPack consumer, whose streams are unknown here
+        self.pins, self.free_pending = 0, False  # recorded graphs that hold this block's address (ekm_hip.graph)
         self._lock = threading.Lock()
         ptr = _cache.take(device, self.stream, self.bucket)
         if ptr is None:
@@ -278,17 +293,32 @@ class _Allocation:
         self.base, self.ptr = ptr, ptr
         _cache.note(device, self.bucket)
         _register_owner(self)
+        cap = _capturing()
+        if cap is not None:
+            cap._adopt(self)
 
     def touch(self, stream):
         """Atomic for the event record / wait only, not for the launch that follows: ONE array must not be used
         from two threads on two different streams at the same time (each thread's launch could slip between the
         other's touch and launch).  Different arrays, or one stream, are fine from any number of threads."""
+        cap = _capturing()
+        if cap is not None:
+            # recording: the graph keeps the block (its address is in the recorded launches) and orders itself after the
+            # block's other users at every launch (Graph.launch); the block enters the recording without an event -- the
+            # device was synchronised when the recording began
+            cap._adopt(self)
+            with self._lock:
+                self.stream = stream
+            return
         with self._lock:
             if stream != self.stream:
                 order_streams(self.device, self.stream, stream)
                 self.stream = stream
 
     def free(self):
+        if self.pins:  # a recorded graph still launches kernels on this address: released when the graph is closed
+            self.free_pending = True
+            return
         if self.ptr:
             ptr, self.ptr, self.base = self.base, None, None
             _cache.note(self.device, -self.bucket)
@@ -326,6 +356,7 @@ class DeviceArray:
 
     @classmethod
     def from_host(cls, array, device=None, dtype=None, capacity=0):
+        _no_capture("an upload (to_device / DeviceArray.from_host / a NumPy or scalar operand)")
         a = np.ascontiguousarray(array, dtype=dtype)
         if a.dtype not in _DTYPES:
             a = a.astype(np.float64)
@@ -364,6 +395,7 @@ class DeviceArray:
 
     # ---- transfers ----
     def copy_from_host(self, array):
+        _no_capture("DeviceArray.copy_from_host")
         a = np.ascontiguousarray(array, dtype=self.dtype)
         if a.size != self.size:
             raise ValueError(f"size mismatch: host {a.size} vs device {self.size}")
@@ -375,6 +407,7 @@ class DeviceArray:
     def copy_from_host_async(self, array):
         """Enqueue the upload on the current stream and return; `array` must stay alive and unchanged until
         the stream has been synchronised (C-contiguous, same dtype and size)."""
+        _no_capture("DeviceArray.copy_from_host_async")
         if array.dtype != self.dtype or array.size != self.size or not array.flags.c_contiguous:
             raise ValueError("copy_from_host_async: need a C-contiguous array of the same dtype and size")
         stream = current_stream()
@@ -382,6 +415,7 @@ class DeviceArray:
         return self
 
     def to_host(self, out=None, sync=True):
+        _no_capture("DeviceArray.to_host")
         if out is None:
             out = np.empty(self.shape, dtype=self.dtype)
         elif out.dtype != self.dtype or out.size != self.size or not out.flags.c_contiguous:

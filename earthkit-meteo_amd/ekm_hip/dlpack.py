@@ -10,7 +10,7 @@ import numpy as np
 
 import threading
 
-from .device import DeviceArray, _register_owner, current_device, current_stream, order_streams
+from .device import DeviceArray, _no_capture, _register_owner, current_device, current_stream, order_streams
 
 kDLROCM = 10
 kDLFloat = 2
@@ -123,6 +123,7 @@ def from_dlpack(obj):
     input type, `array_namespace(*inputs)`, thermo/array/thermo.py:826): `from_dlpack(torch_tensor)`.
     The producer is handed OUR current stream (array-API `__dlpack__(stream=...)`: 0 = default stream on
     ROCm), so it orders its pending work before anything we launch on that stream -- no host wait."""
+    _no_capture("ekm_hip.from_dlpack")  # (the producer would be handed a stream that is recording)
     stream = current_stream()
     if hasattr(obj, "__dlpack__"):
         if hasattr(obj, "__dlpack_device__"):

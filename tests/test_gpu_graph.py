@@ -1,0 +1,102 @@
+"""ekm_hip.graph(): a recorded sequence of thermo calls replays to the bits of the eager calls, follows in-place updates of
+its inputs, and orders itself against uploads and downloads made on other streams."""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "earthkit-meteo_amd")]
+
+pytestmark = pytest.mark.gpu
+
+import ekm_hip  # noqa: E402
+from ekm_hip import thermo  # noqa: E402
+from oracle import synthetic  # noqa: E402
+
+np.seterr(all="ignore")
+NLAT, NLON = 721, 1440  # BASELINE config 2's field
+
+
+def fields(dtype, seed):
+    t, q, p, _ = synthetic.make_fields(1, NLAT * NLON, dtype=dtype, seed=seed)
+    return [x.reshape(NLAT, NLON) for x in (t, q, p)]
+
+
+def eager(host):
+    d = [ekm_hip.to_device(x) for x in host]
+    out = (thermo.relative_humidity_from_specific_humidity(*d), thermo.dewpoint_from_specific_humidity(d[1], d[2]),
+           thermo.potential_temperature(d[0], d[2]), thermo.wet_bulb_temperature_from_specific_humidity(*d),
+           *thermo.pipeline_full(*d))
+    return [o.to_host() for o in out]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_replay_is_the_eager_result_and_follows_its_inputs(dtype):
+    first, second, third = fields(dtype, 3), fields(dtype, 4), fields(dtype, 5)
+    d = [ekm_hip.to_device(x) for x in first]
+    before = ekm_hip.memory_stats()["live_bytes"]
+    with ekm_hip.graph() as g:
+        outs = (thermo.relative_humidity_from_specific_humidity(*d), thermo.dewpoint_from_specific_humidity(d[1], d[2]),
+                thermo.potential_temperature(d[0], d[2]),
+                thermo.wet_bulb_temperature_from_specific_humidity(*d),      # the reference default: bisection, LDS tree
+                *thermo.pipeline_full(*d))
+    assert len(outs) == 10 and all(isinstance(o, ekm_hip.DeviceArray) and o.shape == (NLAT, NLON) and o.dtype == dtype for o in outs)
+    for host in (first, second, third):
+        for dev, h in zip(d, host):
+            dev.copy_from_host(h)            # default stream; the launch is ordered after it
+        g.launch()
+        got = [o.to_host() for o in outs]    # default stream again, ordered after the graph's stream
+        for a, b in zip(got, eager(host)):
+            assert np.array_equal(a, b, equal_nan=True)
+    assert g.launches == 3
+    g.close()
+    del outs, got
+    assert ekm_hip.memory_stats()["live_bytes"] == before
+
+
+def test_scalar_operand_as_a_device_array_and_many_replays():
+    t, _, p = fields(np.float32, 9)
+    dt = ekm_hip.to_device(t)
+    p0 = ekm_hip.to_device(np.float32(85000.0))          # a 0-d DeviceArray: a scalar operand without an upload
+    with ekm_hip.graph() as g:
+        th = thermo.potential_temperature(dt, p0)
+        es = thermo.saturation_vapour_pressure(th)       # a result feeding the next call inside the recording
+    for k in range(20):
+        tk = (t + np.float32(0.25 * k)).astype(np.float32)
+        dt.copy_from_host(tk)
+        g.launch()
+        want_th = thermo.potential_temperature(tk, np.float32(85000.0))
+        assert np.array_equal(th.to_host(), want_th)
+        assert np.array_equal(es.to_host(), thermo.saturation_vapour_pressure(want_th))
+    g.close()
+    assert np.array_equal(th.to_host(), want_th)         # results outlive the graph
+
+
+def test_replay_is_cheaper_than_eager_calls_for_small_fields():
+    d = [ekm_hip.to_device(x) for x in fields(np.float64, 2)]
+    calls = lambda: [thermo.relative_humidity_from_specific_humidity(*d), thermo.dewpoint_from_specific_humidity(d[1], d[2]),  # noqa: E731
+                     thermo.potential_temperature(d[0], d[2]), thermo.saturation_vapour_pressure(d[0])]
+    with ekm_hip.graph() as g:
+        keep = calls()
+    reps = 300
+    for _ in range(20):
+        calls()
+        g.launch()
+    ekm_hip.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        calls()
+    ekm_hip.synchronize()
+    t_eager = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.launch()
+    g.synchronize()
+    t_graph = (time.perf_counter() - t0) / reps
+    print(f"\nfour fp64 calls on 721x1440: eager {1e6 * t_eager:.1f} us, graph replay {1e6 * t_graph:.1f} us per round")
+    assert t_graph < t_eager
+    g.close()
+    del keep

@@ -1,0 +1,159 @@
+"""ekm_hip.graph() host logic without a GPU: the order of the runtime calls, which blocks a recording pins and when it
+lets go of them, and that everything that cannot be recorded raises before HIP is reached.  The library is replaced by a
+recorder (tests/test_gpu_graph.py runs the real thing)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "earthkit-meteo_amd")]
+
+import ekm_hip  # noqa: E402
+from ekm_hip import _ffi, device  # noqa: E402
+
+
+class Recorder:
+    """Stands in for libekm_thermo.so: every function returns 0 and is logged; handles come from a counter."""
+
+    def __init__(self):
+        self.calls, self.next = [], 0x1000
+        self.fail_end = False
+
+    def _handle(self):
+        self.next += 0x100
+        return self.next
+
+    def __getattr__(self, name):
+        def fn(*args):
+            plain = tuple(a for a in args if isinstance(a, (int, type(None))))
+            self.calls.append((name,) + plain)
+            if name in ("ekm_stream_create", "ekm_event_create", "ekm_malloc"):
+                args[-1]._obj.value = self._handle()
+            if name == "ekm_graph_end":
+                if self.fail_end:
+                    return -3
+                if args[-1] is not None:
+                    args[-1]._obj.value = self._handle()
+            if name == "ekm_last_error":
+                return b"graph_end: the capture is invalid"
+            return 0
+
+        return fn
+
+    def names(self):
+        return [c[0] for c in self.calls]
+
+
+@pytest.fixture
+def rec(monkeypatch):
+    r = Recorder()
+    monkeypatch.setattr(_ffi, "lib", lambda: r)
+    monkeypatch.setattr(device._tls, "device", 0, raising=False)
+    monkeypatch.setattr(device._tls, "stream", None, raising=False)
+    monkeypatch.setattr(device, "_cache", device._BlockCache())
+    yield r
+    device._tls.capture = None
+
+
+def test_recording_brackets_and_replay(rec):
+    t = ekm_hip.DeviceArray.empty((4, 8), np.float32)
+    p = ekm_hip.DeviceArray.empty((4, 8), np.float32)
+    rec.calls.clear()
+    with ekm_hip.graph() as g:
+        assert ekm_hip.current_stream() == g.stream and g.stream is not None
+        th = ekm_hip.thermo.potential_temperature(t, p)
+    assert ekm_hip.current_stream() is None
+    assert isinstance(th, ekm_hip.DeviceArray) and th.shape == (4, 8)
+    n = rec.names()
+    # tables first, the device idle, a stream of its own, then the bracket around exactly one kernel launch
+    assert n[:4] == ["ekm_prepare_tables", "ekm_sync", "ekm_stream_create", "ekm_graph_begin"]
+    assert n[-1] == "ekm_graph_end" and n.count("ekm_potential_temperature_f32") == 1
+    assert not any(c.startswith("ekm_event") or c in ("ekm_h2d", "ekm_d2h", "ekm_stream_sync") for c in n[4:-1]), n
+    # the graph holds the two inputs and the result
+    assert {id(a) for a in g._allocs} == {id(t._alloc), id(p._alloc), id(th._alloc)}
+    assert t._alloc.pins == p._alloc.pins == th._alloc.pins == 1 and th._alloc.stream == g.stream
+
+    # an input refreshed on the default stream: the launch orders the graph's stream after it (event record + wait)
+    t._alloc.touch(None)
+    rec.calls.clear()
+    g.launch()
+    n = rec.names()
+    assert n[-1] == "ekm_graph_launch" and n.count("ekm_event_record") == 1 and n.count("ekm_stream_wait_event") == 1
+    assert t._alloc.stream == g.stream
+    rec.calls.clear()
+    g.launch()
+    assert rec.names() == ["ekm_graph_launch"] and g.launches == 2
+
+    # a block the user frees while the graph lives stays allocated until the graph is closed
+    th.free()
+    assert th._alloc.free_pending and th._alloc.ptr
+    rec.calls.clear()
+    stream = g.stream
+    g.close()
+    n = rec.names()
+    assert n[0] == "ekm_stream_sync" and "ekm_graph_destroy" in n and n[-1] == "ekm_stream_destroy"
+    assert th._alloc.ptr is None and t._alloc.pins == 0 and t._alloc.ptr and t._alloc.stream is None
+    assert ("ekm_stream_destroy", 0, stream) in rec.calls
+    g.close()  # idempotent
+    with pytest.raises(ekm_hip.EkmError, match="nothing recorded"):
+        g.launch()
+
+
+def test_what_cannot_be_recorded_raises_before_hip(rec):
+    t = ekm_hip.DeviceArray.empty((16,), np.float32)
+    host = np.ones(16, np.float32)
+    with ekm_hip.graph() as g:
+        rec.calls.clear()
+        for bad in (lambda: ekm_hip.thermo.potential_temperature(t, 85000.0),     # a Python scalar is an upload
+                    lambda: ekm_hip.thermo.potential_temperature(host, host),       # NumPy operands
+                    lambda: t.copy_from_host(host), lambda: t.to_host(), lambda: ekm_hip.to_device(host),
+                    lambda: ekm_hip.synchronize(), lambda: np.asarray(t)):
+            with pytest.raises(ekm_hip.EkmError, match=r"inside an ekm_hip.graph\(\) block"):
+                bad()
+        with pytest.raises(ekm_hip.EkmError, match="do not nest"):
+            ekm_hip.graph().__enter__()
+        assert not any(c in ("ekm_h2d", "ekm_d2h", "ekm_sync", "ekm_stream_sync") for c in rec.names()), rec.names()
+    assert g._exec is not None
+    with pytest.raises(ekm_hip.EkmError, match="recorded already"):
+        g.__enter__()
+    g.close()
+
+
+def test_foreign_arrays_are_refused_while_recording(rec):
+    class Foreign:
+        def __dlpack_device__(self):
+            return (10, 0)
+
+        def __dlpack__(self, stream=None):
+            raise AssertionError("handed a recording stream")
+
+    with ekm_hip.graph() as g:
+        with pytest.raises(ekm_hip.EkmError, match="from_dlpack before the block"):
+            ekm_hip.thermo.saturation_vapour_pressure(Foreign())
+        with pytest.raises(ekm_hip.EkmError, match=r"inside an ekm_hip.graph\(\) block"):
+            ekm_hip.from_dlpack(Foreign())
+    g.close()
+
+
+def test_an_exception_in_the_block_ends_the_recording_and_releases_everything(rec):
+    t = ekm_hip.DeviceArray.empty((16,), np.float32)
+    with pytest.raises(RuntimeError, match="boom"):
+        with ekm_hip.graph() as g:
+            es = ekm_hip.thermo.saturation_vapour_pressure(t)
+            raise RuntimeError("boom")
+    ends = [c for c in rec.calls if c[0] == "ekm_graph_end"]
+    assert len(ends) == 1 and ends[0][-1] is None      # recording dropped: no executable graph asked for
+    assert g.stream is None and g._exec is None and t._alloc.pins == 0 and es._alloc.pins == 0
+    assert ekm_hip.current_stream() is None and device._capturing() is None
+
+
+def test_an_invalid_recording_raises_with_the_library_message(rec):
+    t = ekm_hip.DeviceArray.empty((16,), np.float32)
+    rec.fail_end = True
+    with pytest.raises(ekm_hip.EkmError, match="capture is invalid"):
+        with ekm_hip.graph() as g:
+            ekm_hip.thermo.saturation_vapour_pressure(t)
+    assert g.stream is None and t._alloc.pins == 0 and device._capturing() is None

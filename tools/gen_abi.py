@@ -194,6 +194,15 @@ EKM_API int ekm_event_record(int dev, void* event, void* stream);
 EKM_API int ekm_stream_wait_event(int dev, void* stream, void* event); /* later work on `stream` waits for `event` (no host wait) */
 EKM_API int ekm_event_sync(int dev, void* event);
 EKM_API int ekm_event_elapsed_ms(int dev, void* start, void* stop, float* ms);
+/* HIP graphs: between ekm_graph_begin and ekm_graph_end the launches made on `stream` (from ekm_stream_create; not the
+ * default stream) are RECORDED, not run -- every compute entry point only enqueues kernels, so any sequence of them
+ * can be recorded; ekm_malloc is allowed meanwhile, copies from pageable host memory and waits are not.
+ * ekm_graph_end always ends the recording; it returns the executable graph in *graph_exec (NULL pointer: drop the
+ * recording).  ekm_graph_launch replays it on a stream: same kernels, same pointers, one call. */
+EKM_API int ekm_graph_begin(int dev, void* stream);
+EKM_API int ekm_graph_end(int dev, void* stream, void** graph_exec);
+EKM_API int ekm_graph_launch(int dev, void* graph_exec, void* stream);
+EKM_API int ekm_graph_destroy(int dev, void* graph_exec);
 
 /* ---- launch tuning (process-wide; defaults are the measured best) ---- */
 /* tiles_per_block: consecutive 4-KiB tiles (256 lanes x 16 B) one workgroup streams per field;
