@@ -548,11 +548,12 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
             sp = a if isinstance(a, DeviceArray) and a.dtype == plan.dtype else DeviceArray.from_host(
                 np.ascontiguousarray(np.asarray(a), dtype=plan.dtype), device=dev)
             sp.on(stream)
-            tabs = [DeviceArray.from_host(x.astype(plan.dtype), device=dev) for x in (hp.A, hp.B)]
-            temps.extend(tabs + ([sp] if sp is not a else []))
+            tabs = hp.device_tables(dev, plan.dtype)  # uploaded once per (device, dtype), owned by the HybridPressure
+            if sp is not a:
+                temps.append(sp)
             inner = max(1, sp.size)
             # (a B that is zero in double stays zero in the compute dtype, so the count holds for the uploaded table)
-            operands.append(_ffi.Operand(sp.ptr, _ffi.HYBRID_FULL, hp.nflat, hp.nlev, inner, tabs[0].ptr, tabs[1].ptr))
+            operands.append(_ffi.Operand(sp.ptr, _ffi.HYBRID_FULL, hp.nflat, hp.nlev, inner, tabs[0].on(stream), tabs[1].on(stream)))
             continue
         shape = a.shape
         cls = classify(shape, plan.shape) if plan.n else (_ffi.FIELD, 0, 0)

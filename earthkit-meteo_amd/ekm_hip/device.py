@@ -438,6 +438,7 @@ class DeviceArray:
         waits instead, so that the data is complete for any stream."""
         from .dlpack import to_dlpack
 
+        _no_capture("DeviceArray.__dlpack__")
         last = getattr(self._alloc, "stream", None)
         if stream is None:
             _ffi.check(_ffi.lib().ekm_stream_sync(self.device, last))

@@ -369,6 +369,17 @@ class HybridPressure:
         # them at level-vector speed in a launch of their own (ekm_operand.nflat)
         nz = np.flatnonzero(self.B != 0.0)
         self.nflat = int(max(0, (nz[0] if nz.size else self.B.size) - 1))
+        self._tables = {}  # (device, dtype) -> the two tables in device memory, uploaded once
+
+    def device_tables(self, device, dtype):
+        """A and B in `dtype` on `device`, uploaded at the first use there (synchronously: any stream may read them
+        afterwards) and kept with this object.  Inside an `ekm_hip.graph()` block nothing can be uploaded: use the object
+        once, or call this, before the block."""
+        key = (int(device), np.dtype(dtype).char)
+        tabs = self._tables.get(key)
+        if tabs is None:
+            tabs = self._tables[key] = tuple(DeviceArray.from_host(x.astype(dtype), device=device) for x in (self.A, self.B))
+        return tabs
 
     @property
     def shape(self):

@@ -128,5 +128,53 @@ int main() {
     return 1;
   }
   printf("ekm_prepare_tables: captured bisection launch is one node\n");
+
+  // ---- the ABI's own graph handles (a client without HIP headers): record, allocate meanwhile, replay twice, destroy;
+  // a second recording that is dropped; a default-stream recording refused
+  void* es = nullptr;
+  EKM(ekm_stream_create(0, &es));
+  EKM(ekm_graph_begin(0, es));
+  float* late = nullptr;
+  EKM(ekm_malloc(0, n * 4, (void**)&late));  // relaxed capture: allocation is allowed while recording
+  EKM(ekm_pipeline_svp_td_rh_f32(0, es, &ot, &oq, &op, o[0], o[1], late, n));
+  EKM(ekm_wet_bulb_temperature_from_specific_humidity_f32(0, es, &ot, &oq, &op, EKM_EPT_IFS, EKM_T_BISECT, o[4], n));
+  void* gx = nullptr;
+  EKM(ekm_graph_end(0, es, &gx));
+  if (!gx) {
+    printf("ekm_graph_end returned no executable graph\n");
+    return 1;
+  }
+  for (int round = 0; round < 2; ++round) {
+    EKM(ekm_synth_fill_f32(0, es, t, q, p, 0, n, n / 8, 8, 200 + round));
+    CHK(hipMemsetAsync(late, 0xff, n * 4, static_cast<hipStream_t>(es)));
+    CHK(hipMemsetAsync(o[4], 0xff, n * 4, static_cast<hipStream_t>(es)));
+    EKM(ekm_graph_launch(0, gx, es));
+    EKM(ekm_pipeline_svp_td_rh_f32(0, es, &ot, &oq, &op, r[0], r[1], r[2], n));
+    EKM(ekm_wet_bulb_temperature_from_specific_humidity_f32(0, es, &ot, &oq, &op, EKM_EPT_IFS, EKM_T_BISECT, r[4], n));
+    EKM(ekm_stream_sync(0, es));
+    std::vector<float> a(n), b(n);
+    const float* pairs[2][2] = {{late, r[2]}, {o[4], r[4]}};
+    for (auto& pr : pairs) {
+      CHK(hipMemcpy(a.data(), pr[0], n * 4, hipMemcpyDeviceToHost));
+      CHK(hipMemcpy(b.data(), pr[1], n * 4, hipMemcpyDeviceToHost));
+      if (std::memcmp(a.data(), b.data(), n * 4) != 0 || !(a[777] > 0.0f)) {
+        printf("ekm_graph_launch round %d: replay differs from the direct launch\n", round);
+        return 1;
+      }
+    }
+  }
+  EKM(ekm_graph_destroy(0, gx));
+  EKM(ekm_graph_begin(0, es));
+  EKM(ekm_pipeline_svp_td_rh_f32(0, es, &ot, &oq, &op, o[0], o[1], o[2], n));
+  EKM(ekm_graph_end(0, es, nullptr));  // recording dropped; the stream is usable again
+  EKM(ekm_pipeline_svp_td_rh_f32(0, es, &ot, &oq, &op, o[0], o[1], o[2], n));
+  EKM(ekm_stream_sync(0, es));
+  if (ekm_graph_begin(0, nullptr) >= 0) {
+    printf("ekm_graph_begin accepted the default stream\n");
+    return 1;
+  }
+  EKM(ekm_free(0, late));
+  EKM(ekm_stream_destroy(0, es));
+  printf("ekm_graph_begin/end/launch/destroy: replays identical to direct launches\n");
   return 0;
 }

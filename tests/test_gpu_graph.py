@@ -100,3 +100,35 @@ def test_replay_is_cheaper_than_eager_calls_for_small_fields():
     assert t_graph < t_eager
     g.close()
     del keep
+
+
+def test_hybrid_pressure_inside_a_recording():
+    """Model-level data: the pressure is its hybrid definition (A, B tables + surface pressure), formed inside the kernels.
+    The tables are uploaded once per HybridPressure object -- before the block, because uploads cannot be recorded."""
+    from ekm_hip import vertical
+
+    A, B = vertical.hybrid_level_parameters(137)
+    nlev, npts = 137, 4096
+    rng = np.random.default_rng(17)
+    sp = (101325.0 * (1.0 - 0.3 * rng.random(npts))).astype(np.float32)
+    t = (250.0 + 40.0 * rng.random((nlev, npts))).astype(np.float32)
+    q = (10.0 ** rng.uniform(-6.0, -2.0, (nlev, npts))).astype(np.float32)
+    dt, dq, dsp = (ekm_hip.to_device(x) for x in (t, q, sp))
+    hp = ekm_hip.HybridPressure(A, B, dsp)
+    fresh = ekm_hip.HybridPressure(A, B, dsp)
+    with ekm_hip.graph() as g:
+        with pytest.raises(ekm_hip.EkmError, match=r"inside an ekm_hip.graph\(\) block"):
+            thermo.potential_temperature(dt, fresh)          # its tables are not on the device yet
+    g.close()
+    hp.device_tables(ekm_hip.current_device(), np.float32)
+    with ekm_hip.graph() as g:
+        th = thermo.potential_temperature(dt, hp)
+        tw = thermo.wet_bulb_temperature_from_specific_humidity(dt, dq, hp)
+    for k in range(3):
+        spk = (sp * np.float32(1.0 - 0.01 * k)).astype(np.float32)
+        dsp.copy_from_host(spk)
+        g.launch()
+        hk = ekm_hip.HybridPressure(A, B, spk)
+        assert np.array_equal(th.to_host(), thermo.potential_temperature(t, hk), equal_nan=True)
+        assert np.array_equal(tw.to_host(), thermo.wet_bulb_temperature_from_specific_humidity(t, q, hk), equal_nan=True)
+    g.close()
