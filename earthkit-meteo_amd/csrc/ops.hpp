@@ -206,7 +206,7 @@ struct BisectTable {
   static constexpr int elems = kBisectLattice;
   template <class T>
   static constexpr int count() {
-    return sizeof(T) == 4 ? 3 * kHeapNodes : kBisectLattice * BisectEntry<METHOD, T>::width + 3 * kHeapNodes / 2;
+    return sizeof(T) == 4 ? 3 * kHeapNodes : kBisectLattice + 3 * kHeapNodes / 2;  // fp64: es lattice, then the fp32 tree
   }
   template <class T>
   EKM_HD static void fill(T* __restrict__ tab, int tid, int nthreads) {
@@ -214,7 +214,7 @@ struct BisectTable {
       if constexpr (sizeof(T) == 4) {
         bisect_heap_fill<METHOD>(tab, m);
       } else {
-        BisectEntry<METHOD, T>::fill(tab, m);
+        bisect_es_fill(tab, m);
         bisect_heap_fill<METHOD>(reinterpret_cast<float*>(tab + kBisectLattice), m);
       }
     }

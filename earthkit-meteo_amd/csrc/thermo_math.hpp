@@ -697,8 +697,8 @@ EKM_HD float bisect_step(float r, float dt) { return (r < 0.0f || r > 0.0f) ? __
 EKM_HD double bisect_step(double r, double dt) { return (r < 0.0 || r > 0.0) ? __builtin_copysign(dt, r) : r; }
 EKM_FD fd64<F> bisect_step(fd64<F> r, fd64<F> dt) { return fd64<F>(bisect_step(r.v, dt.v)); }
 
-// Moist-adiabat inversion by 12 fixed halvings (thermo.py:1055-1079), IFS variant, table-free statement (host twin;
-// the gfx950 kernels run t_on_ma_bisect_ifs_tab below, the same arithmetic with es_mixed read from an LDS table).
+// Moist-adiabat inversion by 12 fixed halvings (thermo.py:1055-1079), IFS variant, table-free statement (host twin with
+// EKM_TWIN_TABLE_FREE=1; the gfx950 kernels walk the search tree below, which takes the same decisions from an LDS table).
 //  * The reference's residual ept*exp(G_sat) - t*(p0/p)^kappa (thermo.py:1075) is divided by the positive per-point
 //    constant (p0/p)^kappa: r = te*exp2(g) - t with te = ept*(p/p0)^kappa has the same sign and costs one fma.
 //  * The two divisions of G_sat = -K0*qs/t (thermo.py:1177-1182) are merged into one reciprocal.
@@ -727,13 +727,10 @@ EKM_HD T t_on_ma_bisect_ifs(T e, T p) {
   return t_on_ma_bisect_ifs_te(e * m_exp2(T(k::kappa) * m_log2(p * T(1.0 / k::p0))), p);
 }
 
-// The same 12 halvings with es_mixed read from a table.  The search only ever evaluates the saturated
-// parcel at the lattice temperatures t_m = 253.16 + (m - 2048)*120/2048, m in [1, 4095]: float32(253.16)
-// is a multiple of 2^-15 and every step is a multiple of 15/512, so the reference's accumulated fp32 `t`
-// IS the lattice value, bit for bit (checked exhaustively in tests/test_engine_host.py), and es_mixed(t_m)
-// can be tabulated once per workgroup in LDS (4096 x 4 B = 16 KiB of the 160 KiB).  Per step that replaces
-// 1-2 rcp + 1-2 exp2 + the blend by one ds_read; the residual and its sign are computed exactly as in
-// t_on_ma_bisect_ifs, so the result is bit-identical to it.
+// The search only ever evaluates the saturated parcel at the lattice temperatures t_m = 253.16 + (m - 2048)*120/2048,
+// m in [1, 4095]: float32(253.16) is a multiple of 2^-15 and every step is a multiple of 15/512, so the reference's
+// accumulated fp32 `t` IS the lattice value, bit for bit (checked exhaustively in tests/test_engine_host.py), and
+// everything that depends on t_m alone can be tabulated once per device and kept in LDS.
 constexpr int kBisectLattice = 4096;
 
 template <class T>
@@ -741,12 +738,18 @@ EKM_HD T bisect_lattice_t(int m) {
   return T(k::T0 - 20) + T(m - kBisectLattice / 2) * T(120.0 / 2048);
 }
 
-// One lattice entry: es_m = es_mixed(t_m) and, in fp32, a second value beside it -- the factor of the step's exponent
-// that depends on the lattice temperature alone (LDS: 32 KiB per workgroup in either precision):
-//   ifs       a_m = -K0*eps*log2(e)*es_m/t_m      exponent = a_m * rcp(p + (eps-1)*es_m)
-//   bolton35  a_m = -2675*log2(e)/t_m             exponent = kl + ws*(a_m - 0.28*kl),  kl = kappa*log2(p/p0)
-//   bolton39  a_m = (-3036/t_m + 1.78)*log2(e)    exponent = a_m*ws*(1 + 0.448*ws) + kappa*log2((p - es_m)/p0)
-// fp64 tabulates es alone and forms a_m from t with one reciprocal.
+// Beside es_m = es_mixed(t_m) the tables hold the factor of the step's exponent that depends on t_m alone:
+//   ifs       a_m = -K0*eps*log2(e)*es_m/t_m      exponent g = a_m * rcp(p + (eps-1)*es_m)
+//   bolton35  a_m = -2675*log2(e)/t_m             exponent g = kl + ws*(a_m - 0.28*kl),  kl = kappa*log2(p/p0)
+//   bolton39  a_m = (-3036/t_m + 1.78)*log2(e)    exponent g = a_m*ws*(1 + 0.448*ws) + kappa*log2((p - es_m)/p0)
+// with ws = eps*es_m/(p - es_m).  A step of the search is r = e*exp2(g) - t_m: the reference's residual
+// ept*exp(G_sat) - th_sat (thermo.py:1075) divided by the positive th_sat/t -- for ifs the per-point constant
+// (p0/p)^kappa, folded into e = te (the wet-bulb from q then needs no power of the pressure at all); for bolton35 /
+// bolton39 (thermo.py:1215-1224, 1280-1295) the step's own (p0/p)^(kappa*(1-0.28*ws)) resp. (p0/(p-es))^kappa, whose
+// exponent joins g.  The reference's mask `p - es < eps -> NaN` (thermo.py:192-196, 229-232, 1283-1284: it makes t NaN
+// from that step on) is applied ONCE after the search: fl(p - es) is non-increasing in es, so "some visited lattice
+// point had p - es < eps" is exactly "p - max(es visited) < eps".  Outside the mask p - es >= eps > 0: the unmasked
+// steps stay finite.
 template <int METHOD, class T>
 EKM_HD T bisect_second(T es, T rt) {  // rt = 1/t_m
   if (METHOD == EPT_IFS) return T(-k::K0_ifs * k::eps * k::LOG2E) * es * rt;
@@ -754,106 +757,8 @@ EKM_HD T bisect_second(T es, T rt) {  // rt = 1/t_m
   return m_fma(T(-3036.0), rt, T(1.78)) * T(k::LOG2E);
 }
 
-template <int METHOD, class T>
-struct BisectEntry;
-template <int METHOD>
-struct BisectEntry<METHOD, float> {
-  static constexpr int width = 2;
-  EKM_HD static void fill(float* __restrict__ tab, int m) {
-    const float t = bisect_lattice_t<float>(m), es = es_mixed(t);
-    tab[2 * m] = es;
-    tab[2 * m + 1] = bisect_second<METHOD>(es, 1.0f / t);  // IEEE division: once per workgroup
-  }
-  EKM_HD static void load(const float* __restrict__ tab, int m, float, float& es, float& a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const f2 v = reinterpret_cast<const f2*>(tab)[m];  // one ds_read_b64
-    es = v[0];
-    a = v[1];
-#else
-    es = tab[2 * m];
-    a = tab[2 * m + 1];
-#endif
-  }
-};
-template <int METHOD>
-struct BisectEntry<METHOD, double> {
-  static constexpr int width = 1;
-  EKM_HD static void fill(double* __restrict__ tab, int m) { tab[m] = es_mixed(bisect_lattice_t<double>(m)); }
-  EKM_HD static void load(const double* __restrict__ tab, int m, double, double& es, double& a) {
-    es = tab[m];
-    a = 0.0;  // fp64 forms the t-only factor in the step itself, from the ONE reciprocal it takes (1/(v*t))
-  }
-};
-
-template <int METHOD, bool F>
-struct BisectEntry<METHOD, fd64<F>> {  // the fp64 table read through the wrapper (same layout)
-  static constexpr int width = 1;
-  EKM_HD static void load(const fd64<F>* __restrict__ tab, int m, fd64<F>, fd64<F>& es, fd64<F>& a) {
-    es = tab[m];
-    a = fd64<F>(0.0);
-  }
-};
-
-// The 12 halvings on the table.  `e`: for ifs te = theta_e*(p/p0)^kappa, for the Bolton methods theta_e itself.
-// The reference's residual ept*exp(G_sat) - th_sat (thermo.py:1075) is divided by the positive th_sat/t:
-// r = e*exp2(g) - t has the same sign and costs ONE exp2 and one fma per step.  For ifs th_sat/t = (p0/p)^kappa is a
-// per-point constant (already folded into te; the wet-bulb from q then needs no power of the pressure at all); for
-// bolton35 / bolton39 (thermo.py:1215-1224, 1280-1295) it is the step's own (p0/p)^(kappa*(1-0.28*ws)) resp.
-// (p0/(p-es))^kappa, whose exponent joins g.  The reference's mask `p - es < eps -> NaN` (thermo.py:192-196, 229-232,
-// 1283-1284: it makes t NaN from that step on) is applied ONCE after the search: fl(p - es) is non-increasing in es, so
-// "some visited lattice point had p - es < eps" is exactly "p - max(es visited) < eps" -- one v_max per step instead of
-// a subtract, a compare and a select.  Outside the mask p - es >= eps > 0, so the unmasked steps stay finite.
-// The lattice index is recovered from t itself (t is exactly on the lattice, so (t - 253.16)*2048/120 + 2048 is an
-// integer up to rounding far below 1/2; NaN converts to 0, a valid entry -- the result is NaN from then on anyway).
-template <int METHOD, class T>
-EKM_HD T t_on_ma_bisect_tab(T e, T p, const T* __restrict__ tab) {
-  T t = T(k::T0 - 20);
-  T dt = T(120.0);
-  T esmax = T(0);
-  T kl = T(0);
-  if (METHOD == EPT_BOLTON35) kl = T(k::kappa) * m_log2(p * T(1.0 / k::p0));
-#ifndef EKM_BISECT_UNROLL
-#define EKM_BISECT_UNROLL 12
-#endif
-#pragma unroll EKM_BISECT_UNROLL
-  for (int it = 0; it < 12; ++it) {
-    int m = (int)m_fma(t, T(2048.0 / 120.0), T(kBisectLattice / 2 + 0.5 - (k::T0 - 20) * (2048.0 / 120.0)));
-#if !defined(__HIP_DEVICE_COMPILE__)
-    if (!(t == t)) m = 0;  // v_cvt_i32_f32 turns NaN into 0; the host conversion is undefined
-#endif
-    T es, a, g;
-    BisectEntry<METHOD, T>::load(tab, m, t, es, a);
-    esmax = m_max(esmax, es);
-    const T v = METHOD == EPT_IFS ? m_fma(T(k::eps - 1), es, p) : p - es;
-    T rv;  // 1/v
-    if (BisectEntry<METHOD, T>::width == 2) {
-      rv = m_rcp(v);
-    } else {  // no tabulated a_m: 1/(v*t) gives both 1/v and 1/t (a software reciprocal costs ~35 clocks in fp64)
-      const T r = m_rcp(v * t);
-      rv = r * t;
-      a = bisect_second<METHOD>(es, r * v);
-    }
-    if (METHOD == EPT_IFS) {
-      g = a * rv;  // log2 of exp(-K0*qs/t)
-    } else {
-      const T ws = T(k::eps) * es * rv;
-      if (METHOD == EPT_BOLTON35)
-        g = m_fma(ws, m_fnma(T(0.28), kl, a), kl);
-      else
-        g = m_fma(a * ws, m_fma(T(0.448), ws, T(1)), T(k::kappa) * m_log2(v * T(1.0 / k::p0)));
-    }
-    dt *= T(0.5);
-    t += bisect_step(m_fms(e, m_exp2(g), t), dt);
-  }
-  if ((p - esmax) < T(k::eps_default)) t = nan_v<T>();
-  return t;
-}
-
-template <class T>
-EKM_HD T t_on_ma_bisect_ifs_tab(T te, T p, const T* __restrict__ tab) {
-  return t_on_ma_bisect_tab<EPT_IFS>(te, p, tab);
-}
+// fp64: es_m alone, in lattice order (the fp64 step forms a_m from the ONE reciprocal it takes, 1/(v*t_m))
+EKM_HD void bisect_es_fill(double* __restrict__ tab, int m) { tab[m] = es_mixed(bisect_lattice_t<double>(m)); }
 
 // ---- the IFS search in fp32 as a walk down the search TREE, most steps decided without a transcendental ---------
 // The 12 halvings visit the nodes of a complete binary tree over the lattice: depth d holds the lattice points
@@ -863,7 +768,7 @@ EKM_HD T t_on_ma_bisect_ifs_tab(T te, T p, const T* __restrict__ tab) {
 //
 // The reference decides on r = theta_e*exp(G_sat) - th_sat (thermo.py:1075), i.e. after division by the positive
 // (p0/p)^kappa on  r_m = te*2^(g_m) - t_m,  g_m = a_m/w_m,  w_m = p + (eps - 1)*es_m  (one rcp and one exp2 per step;
-// t_on_ma_bisect_tab above).  In logarithms:  r_m > 0  <=>  log2(te) + g_m > log2(t_m)  <=>  a_m > u_m*w_m  with
+// the stepwise search).  In logarithms:  r_m > 0  <=>  log2(te) + g_m > log2(t_m)  <=>  a_m > u_m*w_m  with
 // u_m = L_m - lte,  L_m = log2(t_m/273.16) tabulated beside (es_m, a_m)  and  lte = log2(te/273.16), which the callers
 // have anyway (the logarithm of te is formed before te is).  D_m = a_m - u_m*w_m is three fused operations.  Its sign
 // is the sign of the reference's fp32 residual whenever |D_m| exceeds what rounding can move either of the two
@@ -872,14 +777,14 @@ EKM_HD T t_on_ma_bisect_ifs_tab(T te, T p, const T* __restrict__ tab) {
 // with |D_m| <= kHeapTau0*p + kHeapTau1*|a_m| (four times those bounds, p >= w) is AMBIGUOUS and is decided by the
 // reference's own arithmetic, evaluated for the wave -- a wave-uniform branch, taken on about two of the twelve steps
 // of a wave (the last ones, where some lane of the wave stands within a millikelvin of its root).  So every decision is
-// the one t_on_ma_bisect_tab takes, bit for bit, at ~10 plain instructions per step instead of 11 + 2 transcendentals.
+// the stepwise search takes, bit for bit, at ~10 plain instructions per step instead of 11 + 2 transcendentals.
 // `all_exact` (tuning parameter bisect_exact) makes every step ambiguous: the stepwise search itself, against which
 // tests/test_gpu_census.py compares the default on every point of the benchmark field.
 //
 // Exactly zero or NaN residuals (the reference then stops moving, resp. turns NaN: `t += sign(r)*dt`) are always
 // ambiguous: the exact branch records the node's temperature (or the NaN) as the lane's final answer, together with the
 // largest es visited so far -- the reference keeps re-evaluating the same point from then on -- for the NaN rule
-// `p - max(es visited) < eps` (thermo.py:192-196, applied once at the end as in t_on_ma_bisect_tab).
+// `p - max(es visited) < eps` (thermo.py:192-196, applied once at the end).
 // Table layout (48 KiB of LDS per workgroup): 4096 pairs (es_i, a_i) in heap order, then the 4096 L_i; node 0 unused.
 constexpr int kHeapNodes = kBisectLattice;
 constexpr double kHeapTau0 = 2.5e-6, kHeapTau1 = 1.2e-6;
@@ -991,7 +896,7 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
       for (int j = 0; j < V; ++j) {
         if (amb[j]) {
           const float tm = bisect_lattice_t<float>(bisect_heap_lattice((int)node[j], d));
-          float g;  // the step of t_on_ma_bisect_tab, operation for operation
+          float g;  // the stepwise search's step (above), operation for operation
           if (METHOD == EPT_IFS) {
             g = a[j] * m_rcp(w[j]);
           } else {
@@ -1030,7 +935,7 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
 
 // The same walk for the fp64 kernels (T = double or fd64): the sign tests run in fp32 on the SAME fp32 tree (the inputs
 // rounded to float: their rounding, <= 6e-8 relative, is far inside the tolerance band), and a step whose test is within
-// the band is decided by the fp64 residual of t_on_ma_bisect_tab -- es from the fp64 lattice table, ONE software
+// the band is decided by the fp64 residual of the stepwise search -- es from the fp64 lattice table, ONE software
 // reciprocal, one software exp2, ~60 fp64 operations -- which the stepwise fp64 search paid at every one of its twelve
 // steps and this walk pays on the few ambiguous ones.  The band is the fp32 one (the fp64 residual's own rounding is
 // nine orders below it), so outside it the fp32 sign IS the sign of the fp64 residual.
@@ -1081,7 +986,7 @@ EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (
         if (amb[j]) {
           const int m = bisect_heap_lattice((int)node[j], d);
           const T tm = bisect_lattice_t<T>(m), es = es_tab[m];
-          // the step of t_on_ma_bisect_tab in T, operation for operation: 1/(v*t) gives both 1/v and 1/t
+          // the stepwise search's step in T, operation for operation: 1/(v*t) gives both 1/v and 1/t
           const T v = METHOD == EPT_IFS ? m_fma(T(k::eps - 1), es, p[j]) : p[j] - es;
           const T r1 = m_rcp(v * tm);
           const T rv = r1 * tm, a = bisect_second<METHOD>(es, r1 * v);

@@ -43,6 +43,9 @@ class Graph:
             raise _ffi.EkmError("ekm_hip.graph() blocks do not nest")
         if self._exec is not None or self.stream is not None:
             raise _ffi.EkmError("this graph has been recorded already; make a new one")
+        if self.device != _device.current_device():
+            raise _ffi.EkmError(f"ekm_hip.graph(device={self.device}) while the current device is {_device.current_device()}: "
+                                "call ekm_hip.set_device first (the block's calls run on the current device)")
         lib = _ffi.lib()
         _ffi.check(lib.ekm_prepare_tables(self.device))   # lookup tables exist before the recording: no fill is recorded
         _ffi.check(lib.ekm_sync(self.device))             # every array enters the recording with its work complete

@@ -113,7 +113,7 @@ def test_leading_axis_bounds(n0, k):
 
 
 def test_bisection_lattice_is_exact_in_fp32():
-    """The LDS table of the IFS bisection (csrc/thermo_math.hpp::t_on_ma_bisect_ifs_tab) relies on this: the
+    """The LDS table of the IFS bisection (csrc/thermo_math.hpp::kBisectLattice, the search tree) relies on this: the
     reference's accumulated fp32 temperature (thermo.py:1055-1079: t = 253.16; dt /= 2; t += sign*dt) equals
     253.16f + M*120/2048 bit for bit at each of the 12 evaluations, for EVERY one of the 2^11 sign paths."""
     t0 = np.float32(273.16 - 20)
