@@ -236,7 +236,7 @@ __device__ __forceinline__ void load_op_table(T* __restrict__ lds) {
 // pointer per stream, carried round the tile loop and alive across the whole body, and paid for them with 12-88 B of
 // scratch memory per lane (bolton35 bisection 4.87 -> 4.55 ms without it).  Kernels with registers to spare keep the
 // running pointers: the six-output pipeline measured 2 % slower with late addresses, and so did the per-level tree
-// walks, which never spilled (profiles/r04_late_index.txt).
+// walks, which never spilled (profiles/r04_tree_walk_tuning.txt).
 template <class Op, class T>
 __device__ __forceinline__ unsigned long long late_index(unsigned long long i) {
   if constexpr (OpThreads<Op, T>::tree) asm volatile("" : "+v"(i));

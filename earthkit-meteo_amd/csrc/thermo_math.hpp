@@ -416,6 +416,14 @@ EKM_HD T m_sign(T x) {
 // waves of warm-only / cold-only / non-regime points skip work); on the host it is the
 // plain per-point condition.  Purely an execution shortcut: lanes that need a value
 // always get it computed.
+// EKM_WAVE_MASK(cond): the wave's lanes where cond holds, as a 64-bit mask (host: 0 / 1).  Masks of several fresh
+// comparisons OR-ed together and tested against zero stay on the scalar unit (s_or_b64 + s_cmp), where OR-ing the
+// conditions first and balloting the result costs a v_cndmask + v_cmp per test.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EKM_WAVE_MASK(cond) (__builtin_amdgcn_ballot_w64(cond))
+#else
+#define EKM_WAVE_MASK(cond) ((cond) ? 1ull : 0ull)
+#endif
 #if defined(EKM_NO_WAVE_SKIP)
 #define EKM_ANY(cond) (true)
 #elif defined(__HIP_DEVICE_COMPILE__)
@@ -872,7 +880,8 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
 #pragma unroll
   for (int d = 0; d < 12; ++d) {
     float es[V], a[V], w[V], D[V];
-    bool amb[V], any = false;
+    bool amb[V];
+    unsigned long long any = 0ull;  // lanes of the wave with an ambiguous test at this depth, over the V points
 #pragma unroll
     for (int j = 0; j < V; ++j) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -888,10 +897,10 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
       D[j] = bisect_fast_test<METHOD>(es[j], a[j], u, p[j], kl[j], w[j], thr0[j], amb[j]);
       const unsigned eb = __builtin_bit_cast(unsigned, es[j]);
       esmax[j] = esmax[j] > eb ? esmax[j] : eb;
+      any |= EKM_WAVE_MASK(amb[j]);
       amb[j] = amb[j] || all_exact;
-      any = any || amb[j];
     }
-    if (EKM_ANY(any)) {  // the reference's own residual for the lanes that need it
+    if (any != 0ull || all_exact) {  // (wave-uniform) the reference's own residual for the lanes that need it
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         if (amb[j]) {
@@ -964,7 +973,8 @@ EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (
 #pragma unroll
   for (int d = 0; d < 12; ++d) {
     float D[V];
-    bool amb[V], any = false;
+    bool amb[V];
+    unsigned long long any = 0ull;  // lanes of the wave with an ambiguous test at this depth, over the V points
 #pragma unroll
     for (int j = 0; j < V; ++j) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -977,10 +987,10 @@ EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (
       const float u = *reinterpret_cast<const float*>(logs + (node[j] << 2)) - ltef[j];
       float w;
       D[j] = bisect_fast_test<METHOD>(es, a, u, pf[j], klf[j], w, thr0[j], amb[j]);  // (the band is wide enough for the
-      amb[j] = amb[j] || all_exact;                                                  //  inputs' rounding to float)
-      any = any || amb[j];
+      any |= EKM_WAVE_MASK(amb[j]);                                                  //  inputs' rounding to float)
+      amb[j] = amb[j] || all_exact;
     }
-    if (EKM_ANY(any)) {
+    if (any != 0ull || all_exact) {
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         if (amb[j]) {
