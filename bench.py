@@ -748,7 +748,7 @@ def rocprof_pass(args, counters, steps=3, warm=1):
                 if row["Counter_Name"] in counters:
                     agg[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
         # the kernels of the timed step: launched warm-up + steps times (fill / table kernels run once)
-        ks = {k: dict(v) for k, v in agg.items() if any(t in k for t in ("map_", "geopotential_columns", "hybrid_levels"))
+        ks = {k: dict(v) for k, v in agg.items() if any(t in k for t in ("map_", "geopotential_columns", "hybrid_levels", "hybrid_rows"))
               and all(len(x) == steps + warm for x in v.values())}
         if not ks:
             return None, f"no kernel with {steps + warm} launches in the {' '.join(counters)} pass"

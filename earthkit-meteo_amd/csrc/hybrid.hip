@@ -112,6 +112,72 @@ __global__ __launch_bounds__(kThreads) void hybrid_levels(const T* __restrict__ 
   }
 }
 
+// The same outputs with one workgroup per (level, tile): every output row is written by workgroups dispatched in order,
+// like a map kernel's stream, instead of each workgroup visiting all rows of its column strip 26 MB apart -- the walk that
+// cost the column kernel its address translations (58 x the UTCL1 misses of a map kernel, the level-2 translation cache
+// busy 80 % of the time: profiles/r04_columns_pmc.txt).  Nothing is carried from level to level here: both half-level
+// pressures of the layer are formed from sp (one fma more per element), and sp is re-read once per level from L2 --
+// the grid runs bands of EKM_HYBRID_BAND_KB of surface pressure, all levels of a band before the next band, as the
+// thermo kernels do in EKM_HYBRID_FULL mode.  blockIdx.y = nfull is the extra row of `half`.
+// Same expressions as hybrid_levels, element for element: the two kernels agree bit for bit (tests/test_gpu_vertical.py).
+template <class T>
+__global__ __launch_bounds__(kThreads) void hybrid_rows(const T* __restrict__ A, const T* __restrict__ B,
+                                                       const T* __restrict__ sp, unsigned long long npts, unsigned nfull,
+                                                       const int* __restrict__ row_full, const int* __restrict__ row_half,
+                                                       int top_is_zero, T alpha_top, T* __restrict__ full,
+                                                       T* __restrict__ half, T* __restrict__ delta, T* __restrict__ alpha,
+                                                       int vec_ok) {
+  constexpr int V = VecOf<T>::N;
+  typedef typename VecOf<T>::type Vec;
+  const unsigned k = blockIdx.y;  // wave-uniform
+  const int rf = k < nfull ? (row_full ? row_full[k] : (int)k) : -1;
+  const int rh = half ? (row_half ? row_half[k] : (int)k) : -1;
+  if (rf < 0 && rh < 0) return;  // a level the caller did not select
+  const unsigned long long tile = (unsigned long long)blockIdx.z * gridDim.x + blockIdx.x;
+  const unsigned long long i0 = (tile * kThreads + threadIdx.x) * V;
+  if (i0 >= npts) return;
+  const bool whole = vec_ok && (i0 + V <= npts);
+  Vec s;
+  if (whole) {
+    s = *reinterpret_cast<const Vec*>(sp + i0);  // cached: the other levels of the band re-read it
+  } else {
+#pragma unroll
+    for (int j = 0; j < V; ++j) s[j] = (i0 + j < npts) ? sp[i0 + j] : T(1);
+  }
+  auto put = [&](T* base, int row, const Vec& v) {
+    T* dst = base + (unsigned long long)row * npts + i0;
+    if (whole) {
+      st_stream<T>(dst, v);
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j)
+        if (i0 + j < npts) dst[j] = v[j];
+    }
+  };
+  const Vec ph = A[k] + B[k] * s;
+  if (rh >= 0) put(half, rh, ph);
+  if (rf < 0) return;
+  const Vec phn = A[k + 1] + B[k + 1] * s;
+  if (full) put(full, rf, ph + T(0.5) * (phn - ph));
+  if (delta || alpha) {
+    Vec d, a;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      if (k == 0 && top_is_zero) {
+        d[j] = log(phn[j] / T(0.1));
+        a[j] = alpha_top;
+      } else {
+        T dj, aj;
+        layer_delta_alpha(ph[j], phn[j], dj, aj);
+        d[j] = dj;
+        a[j] = aj;
+      }
+    }
+    if (delta) put(delta, rf, d);
+    if (alpha) put(alpha, rf, a);
+  }
+}
+
 // any(a0 + b0*sp <= thresh): the reference's global test for a zero-pressure model top
 template <class T>
 __global__ __launch_bounds__(kThreads) void any_le(const T* __restrict__ sp, unsigned long long n, T a0, T b0, T thresh,
@@ -326,9 +392,20 @@ static int launch_hybrid(int dev, void* stream, const T* A, const T* B, const T*
   const unsigned long long nchunk = (npts + V - 1) / V;
   const unsigned long long grid = (nchunk + kThreads - 1) / kThreads;
   if (grid > 0x7fffffffull) return set_error(EKM_ERR_ARG, "pressure_on_hybrid_levels: too many columns");
-  hipLaunchKernelGGL((hybrid_levels<T>), dim3((unsigned)grid), dim3(kThreads), 0, static_cast<hipStream_t>(stream), A,
-                     B, sp, (unsigned long long)npts, nfull, row_full, row_half, top_is_zero, alpha_top, full, half,
-                     delta, alpha, vec_ok);
+  const unsigned rows = nfull + (half ? 1u : 0u);
+  if (tuning_hybrid_rows() && rows <= 65535u) {
+    unsigned long long band = (unsigned long long)tuning_hybrid_band_bytes() / ((unsigned long long)kThreads * V * sizeof(T));
+    if (band < 8) band = 8;
+    if (band > grid) band = grid;
+    while ((grid + band - 1) / band > 65535ull) band *= 2;
+    hipLaunchKernelGGL((hybrid_rows<T>), dim3((unsigned)band, rows, (unsigned)((grid + band - 1) / band)), dim3(kThreads), 0,
+                       static_cast<hipStream_t>(stream), A, B, sp, (unsigned long long)npts, nfull, row_full, row_half,
+                       top_is_zero, alpha_top, full, half, delta, alpha, vec_ok);
+  } else {
+    hipLaunchKernelGGL((hybrid_levels<T>), dim3((unsigned)grid), dim3(kThreads), 0, static_cast<hipStream_t>(stream), A,
+                       B, sp, (unsigned long long)npts, nfull, row_full, row_half, top_is_zero, alpha_top, full, half,
+                       delta, alpha, vec_ok);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(EKM_ERR_HIP, "hybrid_levels launch: %s", hipGetErrorString(e));
   return EKM_OK;

@@ -616,6 +616,7 @@ int tuning_hybrid_band_bytes();  // EKM_HYBRID_FULL: bytes of surface pressure p
 int tuning_table_tiles();   // most tiles per workgroup for ops that keep an LDS table (EKM_TABLE_TILES, default 0 = by op)
 int tuning_bisect_exact();   // fp32 IFS bisection: 1 = the reference's residual at every step of the tree walk (EKM_BISECT_EXACT, default 0)
 int tuning_f64_plain();      // fp64 map kernels: 1 = every lane redone in plain double (EKM_F64_PLAIN, default 0)
+int tuning_hybrid_rows();     // pressure_on_hybrid_levels: 1 = one workgroup per (level, tile), rows written in order (EKM_HYBRID_ROWS, default 1); 0 = one lane per column
 int tuning_geo_chunk_levels();  // levels per launch of the geopotential column scan (EKM_GEO_CHUNK_LEVELS, default: all in one launch)
 
 constexpr unsigned kMaxLdsBytes = 32 * 1024;  // staged level vectors (dynamic LDS); an op's own table (static, up to 80 KiB) comes on top

@@ -106,6 +106,7 @@ static Param g_params[] = {
     {"geo_chunk_levels", "EKM_GEO_CHUNK_LEVELS", 1 << 20, 1, 1 << 20},
     {"f64_plain", "EKM_F64_PLAIN", 0, 0, 1},
     {"bisect_exact", "EKM_BISECT_EXACT", 0, 0, 1},
+    {"hybrid_rows", "EKM_HYBRID_ROWS", 1, 0, 1},
 };
 static int param(int i) {
   int v = g_params[i].value.load(std::memory_order_relaxed);
@@ -121,6 +122,7 @@ int tuning_table_tiles() { return param(2); }
 int tuning_geo_chunk_levels() { return param(3); }
 int tuning_f64_plain() { return param(4); }
 int tuning_bisect_exact() { return param(5); }
+int tuning_hybrid_rows() { return param(6); }
 
 
 // ---- synthetic atmosphere on the device (SURVEY.md 8d distribution) ---------
@@ -536,7 +538,7 @@ int ekm_set_tuning_param(const char* name, int value) {
       return EKM_OK;
     }
   }
-  return set_error(EKM_ERR_ARG, "set_tuning_param: unknown parameter '%s' (lev_per_wg, hybrid_band_kb, table_tiles, geo_chunk_levels, f64_plain, bisect_exact)", name);
+  return set_error(EKM_ERR_ARG, "set_tuning_param: unknown parameter '%s' (lev_per_wg, hybrid_band_kb, table_tiles, geo_chunk_levels, f64_plain, bisect_exact, hybrid_rows)", name);
 }
 
 int ekm_synth_fill_f32(int dev, void* stream, float* t, float* q, float* p, uint64_t first, size_t n, uint64_t inner,

@@ -316,3 +316,29 @@ def test_geopotential_scan_in_level_chunks_equals_one_launch(ek):
         _ffi.check(lib.ekm_set_tuning_param(b"geo_chunk_levels", 1 << 20))
     for k in (2, 4):
         assert np.array_equal(outs[0], outs[k], equal_nan=True) and np.array_equal(outs[1], outs[k + 1], equal_nan=True)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_row_ordered_and_column_kernels_agree_bit_for_bit(ek, dt):
+    """pressure_on_hybrid_levels runs one workgroup per (level, tile) by default (tuning parameter hybrid_rows = 1); the
+    round-2 kernel -- one lane per column, walking down the levels -- is the same arithmetic: every output, level
+    selections, ragged and unaligned column counts, a zero-pressure model top."""
+    from ekm_hip import _ffi
+
+    lib = _ffi.lib()
+    A, B = G["coef.137.A"].astype(dt), G["coef.137.B"].astype(dt)
+    rng = np.random.default_rng(23)
+    try:
+        for npts, levels, output in ((4096, None, ["full", "half", "delta", "alpha"]), (1031, None, ["full"]),
+                                     (8193, [1, 2, 50, 137], ["half", "alpha"]), (64 * 1024 + 2, [90, 91, 137], ["delta", "full"]),
+                                     (3, None, ["full", "half"])):
+            sp = ek.to_device(rng.uniform(5e4, 1.05e5, npts).astype(dt))
+            got = {}
+            for rows in (1, 0):
+                _ffi.check(lib.ekm_set_tuning_param(b"hybrid_rows", rows))
+                res = ek.vertical.pressure_on_hybrid_levels(A, B, sp, levels=levels, output=output)
+                got[rows] = [r.to_host() for r in (res if isinstance(res, tuple) else (res,))]
+            for name, a, b in zip(output, got[1], got[0]):
+                assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), (npts, levels, name)
+    finally:
+        _ffi.check(lib.ekm_set_tuning_param(b"hybrid_rows", 1))

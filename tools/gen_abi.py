@@ -214,6 +214,8 @@ EKM_API int ekm_get_tuning(int* tiles_per_block, int* unroll);
  *   "lev_per_wg"     [EKM_LEV_PER_WG, 0]         EKM_HYBRID_FULL, one-in one-out functions only (theta ...): consecutive levels one workgroup walks (0 = 4); no effect on functions with more streams or on the bisection functions;
  *   "table_tiles"    [EKM_TABLE_TILES, 0]        most tiles per workgroup for ops that keep an LDS table (bisection); 0 = by op (8 or 16);
  *   "geo_chunk_levels" [EKM_GEO_CHUNK_LEVELS, all] levels per launch of the geopotential column scan;
+ *   "hybrid_rows"      [EKM_HYBRID_ROWS, 1]        pressure_on_hybrid_levels: 1 = one workgroup per (level, tile), every output row
+ *                      written in order like a map kernel's stream; 0 = one lane per column walking down the levels; same results;
  *   "f64_plain"        [EKM_F64_PLAIN, 0]          1: the fp64 map kernels redo EVERY lane with the plain-double primitives
  *                      (IEEE special operands fixed up as libm does) instead of only the lanes whose fast first pass
  *                      produced a non-finite output; same results, for tests and A/B timing;

@@ -28,7 +28,7 @@ for d in sorted(glob.glob(os.path.join(O, "pass*_*"))):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    ks = [k for k in agg if any(t in k for t in ("map_", "geopotential_columns", "hybrid_levels")) and "fill" not in k]
+    ks = [k for k in agg if any(t in k for t in ("map_", "geopotential_columns", "hybrid_levels", "hybrid_rows")) and "fill" not in k]
     if not ks:
         continue
     k = max(ks, key=lambda k: len(next(iter(agg[k].values()))))

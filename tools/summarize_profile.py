@@ -39,7 +39,7 @@ def main():
     traffic = {}
     for r in rows:
         name = r["Name"]
-        if not any(k in name for k in ("map_", "geopotential_columns", "hybrid_levels")):
+        if not any(k in name for k in ("map_", "geopotential_columns", "hybrid_levels", "hybrid_rows")):
             continue
         rd = 2.0 * fetch.get(name, 0.0) * 1024.0
         wr = write.get(name, 0.0) * 1024.0
