@@ -211,12 +211,60 @@ def run(name, args, ints=(), eps=None, dtype=None):
     """Launch entry point `name` on `args`; returns a tuple of outputs.  NumPy inputs that are large
     (>= 256 MB), or any NumPy inputs inside `ekm_hip.multi_gpu()`, are streamed through the GPU(s) in
     slices of their leading axis with a bounded device working set (`_run_streamed`)."""
-    from .device import current_devices
-
+    if dtype is None:
+        recipe = _recipes.get(_recipe_key(name, args, ints))  # every operand a DeviceArray and the call seen before
+        if recipe is not None and not _sharding():
+            return _run_remembered(recipe, args, eps)
     args, foreign = _adopt_foreign(args)
     if foreign is not None:
         return _hand_back(_run(name, args, ints, eps, dtype), foreign)
     return _run(name, args, ints, eps, dtype)
+
+
+# ---- the device-resident call, remembered ---------------------------------------------------------------------------
+# A thermo call on DeviceArrays is one kernel launch of ~10 us on a field of a million points; planning it (dtype
+# promotion, broadcasting, how each operand reaches the kernel) costs more than that in Python.  The plan depends only on
+# the entry point, its enum arguments and each operand's (shape, dtype, device): the first such call goes the general way
+# and leaves a recipe behind (`_submit`), later ones with the same key launch from it.
+_recipes = {}
+_RECIPES_MAX = 512
+
+
+class _Recipe:
+    __slots__ = ("fn", "device", "dtype", "shape", "n", "nbytes", "classes", "ints", "nout", "has_eps")
+
+
+def _recipe_key(name, args, ints):
+    try:
+        return (name, tuple(ints)) + tuple([(a.shape, a.dtype.char, a.device) if type(a) is DeviceArray else _NOT_DEVICE for a in args])
+    except TypeError:  # an unhashable enum argument: the general path reports it
+        return None
+
+
+_NOT_DEVICE = object()  # never part of a stored key: a call with any other operand type misses
+
+
+def _sharding():
+    """Inside `multi_gpu()` with more than one device (the general path explains why device-resident inputs cannot be sharded)."""
+    from .device import current_devices
+
+    devs = current_devices()
+    return bool(devs) and len(devs) > 1
+
+
+def _run_remembered(rec, args, eps):
+    stream = current_stream()
+    operands = [_ffi.Operand(a.on(stream), c[0], 0, c[1], c[2]) for a, c in zip(args, rec.classes)]
+    results = [DeviceArray._new(rec.shape, rec.dtype, rec.device, rec.nbytes) for _ in range(rec.nout)]
+    cargs = [rec.device, stream]
+    cargs += [C.byref(o) for o in operands]
+    cargs += rec.ints
+    if rec.has_eps:
+        cargs.append(float(eps))
+    cargs += [r.ptr for r in results]
+    cargs.append(rec.n)
+    _ffi.check(rec.fn(*cargs))
+    return tuple(results)
 
 
 def _run(name, args, ints, eps, dtype):
@@ -584,6 +632,15 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
         cargs.append(float(eps))
     cargs += [r.ptr for r in results] + [plan.n]
     _ffi.check(fn(*cargs))
+    if (not temps and plan.on_device and not plan.hybrid and dtype is None and host_out is None and reserve_rows is None
+            and plan.n and len(_recipes) < _RECIPES_MAX and all(type(a) is DeviceArray for a in args)):
+        rec = _Recipe()
+        rec.fn, rec.device, rec.dtype, rec.shape, rec.n = fn, dev, plan.dtype, plan.shape, plan.n
+        rec.nbytes, rec.nout, rec.has_eps = plan.n * plan.dtype.itemsize, len(outs), has_eps
+        rec.classes, rec.ints = [(o.mode, o.len, o.inner) for o in operands], [int(v) for v in ints]
+        key = _recipe_key(name, args, ints)
+        if key is not None:
+            _recipes[key] = rec
     pend = _Pending()
     pend.plan, pend.results, pend.temps, pend.host_out = plan, results, temps, host_out
     pend.internal_out, pend.toucher, pend.stream = internal_out, toucher, stream

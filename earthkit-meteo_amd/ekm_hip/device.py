@@ -355,6 +355,12 @@ class DeviceArray:
         return cls(alloc, alloc.ptr, shape, dtype, device)
 
     @classmethod
+    def _new(cls, shape, dtype, device, nbytes):
+        """`empty` for arguments that are normalised already (a tuple of ints, a np.dtype of ours, the byte count)."""
+        alloc = _Allocation(nbytes, device)
+        return cls(alloc, alloc.ptr, shape, dtype, device)
+
+    @classmethod
     def from_host(cls, array, device=None, dtype=None, capacity=0):
         _no_capture("an upload (to_device / DeviceArray.from_host / a NumPy or scalar operand)")
         a = np.ascontiguousarray(array, dtype=dtype)

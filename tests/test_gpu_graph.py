@@ -132,3 +132,34 @@ def test_hybrid_pressure_inside_a_recording():
         assert np.array_equal(th.to_host(), thermo.potential_temperature(t, hk), equal_nan=True)
         assert np.array_equal(tw.to_host(), thermo.wet_bulb_temperature_from_specific_humidity(t, q, hk), equal_nan=True)
     g.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_remembered_plans_give_the_first_call_s_results(dtype):
+    """_engine.run plans a device-resident call once and launches repeats from the recipe: field, level-vector and scalar
+    operands, enum and eps arguments -- the repeat equals the planned call (and the NumPy path) bit for bit."""
+    from ekm_hip import _engine
+
+    nlev, npts = 12, 2048
+    t, q, p, _ = synthetic.make_fields(nlev, npts, dtype=dtype, seed=21)
+    t, q, p = (x.reshape(nlev, npts) for x in (t, q, p))
+    lev = p[:, :1].copy()
+    dt, dq, dp, dlev = (ekm_hip.to_device(x) for x in (t, q, p, lev))
+    one = ekm_hip.to_device(dtype(85000.0))
+    cases = [
+        (lambda a: thermo.pipeline_full(*a), (dt, dq, dp), (t, q, p)),
+        (lambda a: thermo.wet_bulb_temperature_from_specific_humidity(*a), (dt, dq, dlev), (t, q, lev)),
+        (lambda a: thermo.wet_bulb_temperature_from_specific_humidity(*a, ept_method="bolton35", t_method="newton"), (dt, dq, dp), (t, q, p)),
+        (lambda a: thermo.potential_temperature(*a), (dt, one), (t, dtype(85000.0))),
+        (lambda a: thermo.saturation_mixing_ratio_slope(*a, phase="ice", eps=2e-4), (dt, dp), (t, p)),
+    ]
+    _engine._recipes.clear()
+    for fn, dev_args, host_args in cases:
+        before = len(_engine._recipes)
+        first = fn(dev_args)
+        assert len(_engine._recipes) == before + 1
+        again = fn(dev_args)
+        want = fn(host_args)
+        for a, b, w in zip(*[(x if isinstance(x, tuple) else (x,)) for x in (first, again, want)]):
+            assert isinstance(b, ekm_hip.DeviceArray) and np.array_equal(a.to_host(), b.to_host(), equal_nan=True)
+            assert np.array_equal(b.to_host(), w, equal_nan=True)

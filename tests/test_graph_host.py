@@ -19,7 +19,7 @@ class Recorder:
     """Stands in for libekm_thermo.so: every function returns 0 and is logged; handles come from a counter."""
 
     def __init__(self):
-        self.calls, self.next = [], 0x1000
+        self.calls, self.operands, self.next = [], [], 0x1000
         self.fail_end = False
 
     def _handle(self):
@@ -28,8 +28,10 @@ class Recorder:
 
     def __getattr__(self, name):
         def fn(*args):
-            plain = tuple(a for a in args if isinstance(a, (int, type(None))))
+            plain = tuple(a for a in args if isinstance(a, (int, float, type(None))))
             self.calls.append((name,) + plain)
+            self.operands.append([(o._obj.data, o._obj.mode, o._obj.len, o._obj.inner) for o in args
+                                  if hasattr(o, "_obj") and isinstance(o._obj, _ffi.Operand)])
             if name in ("ekm_stream_create", "ekm_event_create", "ekm_malloc"):
                 args[-1]._obj.value = self._handle()
             if name == "ekm_graph_end":
@@ -157,3 +159,42 @@ def test_an_invalid_recording_raises_with_the_library_message(rec):
         with ekm_hip.graph() as g:
             ekm_hip.thermo.saturation_vapour_pressure(t)
     assert g.stream is None and t._alloc.pins == 0 and device._capturing() is None
+
+
+def test_a_device_resident_call_is_planned_once_and_launched_from_the_recipe(rec, monkeypatch):
+    """_engine.run: the first call with DeviceArray operands of given shapes / dtypes leaves a recipe behind; the next one
+    skips the planning and must hand the library exactly the same arguments (new result pointers aside)."""
+    from ekm_hip import _engine
+
+    monkeypatch.setattr(_engine, "_recipes", {})
+    t = ekm_hip.DeviceArray.empty((5, 6, 64), np.float32)
+    q = ekm_hip.DeviceArray.empty((5, 6, 64), np.float32)
+    lev = ekm_hip.DeviceArray.empty((5, 1, 1), np.float32)      # a level vector: LEVEL_MAJOR operand
+    one = ekm_hip.DeviceArray.empty((), np.float32)             # a scalar operand
+    planned = []
+    real_plan = _engine._Plan
+    monkeypatch.setattr(_engine, "_Plan", lambda *a, **k: planned.append(1) or real_plan(*a, **k))
+    for args, call in (((t, q, lev), lambda: ekm_hip.thermo.wet_bulb_temperature_from_specific_humidity(t, q, lev, ept_method="bolton39", t_method="newton")),
+                       ((t, one), lambda: ekm_hip.thermo.potential_temperature(t, one)),
+                       ((t, q, lev), lambda: ekm_hip.thermo.saturation_mixing_ratio_slope(t, lev, eps=2e-4) if False else ekm_hip.thermo.pipeline_full(t, q, lev))):
+        planned.clear()
+        rec.calls.clear()
+        rec.operands.clear()
+        first, second, third = call(), call(), call()
+        assert len(planned) == 1, planned                      # planned once, launched three times
+        launches = [(c, o) for c, o in zip(rec.calls, rec.operands) if c[0].endswith("_f32") and "malloc" not in c[0]]
+        assert len(launches) == 3
+        nres = len(first) if isinstance(first, tuple) else 1
+        strip = lambda c: c[:len(c) - nres - 1] + c[-1:]       # noqa: E731  (result pointers differ from call to call)
+        assert strip(launches[0][0]) == strip(launches[1][0]) == strip(launches[2][0]), launches
+        assert launches[0][1] == launches[1][1] == launches[2][1] and len(launches[0][1]) == len(args)
+        for a, b in zip(first if isinstance(first, tuple) else (first,), second if isinstance(second, tuple) else (second,)):
+            assert a.shape == b.shape == (5, 6, 64) and a.dtype == b.dtype == np.float32 and a.ptr != b.ptr
+    # a different shape, dtype or enum argument is a different plan; NumPy operands never take the recipe
+    planned.clear()
+    ekm_hip.thermo.potential_temperature(t.reshape(30, 64), one)
+    ekm_hip.thermo.wet_bulb_temperature_from_specific_humidity(t, q, lev, ept_method="ifs", t_method="newton")
+    assert len(planned) == 2
+    monkeypatch.setattr(device._tls, "devices", (0, 1), raising=False)   # as inside ekm_hip.multi_gpu([0, 1])
+    with pytest.raises(ekm_hip.EkmError, match="multi_gpu"):
+        ekm_hip.thermo.potential_temperature(t, one)            # remembered, but sharding goes the general way (and refuses)
