@@ -367,6 +367,17 @@ int ekm_memset(int dev, void* dst, int value, size_t bytes, void* stream) {
   return EKM_OK;
 }
 
+// `count` 32-bit words set to `value`, asynchronously on `stream`: how a host-side scalar (its bit pattern) reaches device
+// memory without a host buffer -- nothing to keep alive, no wait, and recordable into a graph.
+int ekm_fill_u32(int dev, void* dst, uint32_t value, size_t count, void* stream) {
+  if (count == 0) return EKM_OK;
+  if (!dst || reinterpret_cast<uintptr_t>(dst) % 4) return set_error(EKM_ERR_ARG, "fill_u32: null or unaligned pointer");
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  EKM_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dst), (int)value, count, static_cast<hipStream_t>(stream)));
+  return EKM_OK;
+}
+
 int ekm_sync(int dev) {
   int rc = use_device(dev);
   if (rc != EKM_OK) return rc;

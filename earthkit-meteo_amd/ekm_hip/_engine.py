@@ -613,6 +613,16 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
                 lds_bytes += (nb + 15) & ~15
         if isinstance(a, DeviceArray) and cls is not None and a.dtype == plan.dtype:
             darr = a
+        elif cls is not None and cls[0] == _ffi.SCALAR and not isinstance(a, DeviceArray):
+            # a host scalar: its bit pattern written by an asynchronous fill (one 32-bit word, two for fp64) -- no host
+            # buffer to keep alive, no synchronous copy (which cost more than the kernel of a small call), and
+            # recordable inside ekm_hip.graph()
+            words = np.asarray(a, dtype=plan.dtype).reshape(1).view(np.uint32)
+            darr = DeviceArray.empty((), plan.dtype, dev)
+            base = darr.on(stream)
+            for w in range(words.size):
+                _ffi.check(lib.ekm_fill_u32(dev, base + 4 * w, int(words[w]), 1, stream))
+            temps.append(darr)
         else:
             h = np.asarray(a)  # DeviceArray -> host copy only on the slow path
             if cls is None:

@@ -57,6 +57,7 @@ def _signatures():
         "ekm_host_prefault": ([vp, sz, i], i),
         "ekm_h2d": ([i, vp, vp, sz, vp], i), "ekm_d2h": ([i, vp, vp, sz, vp], i),
         "ekm_d2d": ([i, vp, vp, sz, vp], i), "ekm_memset": ([i, vp, i, sz, vp], i),
+        "ekm_fill_u32": ([i, vp, u32, sz, vp], i),
         "ekm_sync": ([i], i),
         "ekm_stream_create": ([i, pvp], i), "ekm_stream_destroy": ([i, vp], i), "ekm_stream_sync": ([i, vp], i),
         "ekm_event_create": ([i, pvp], i), "ekm_event_destroy": ([i, vp], i),

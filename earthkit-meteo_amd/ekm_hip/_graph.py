@@ -15,8 +15,9 @@ HIP call:
         use(rh.to_host(), td.to_host())
     g.close()
 
-Rules: every operand inside the block is a DeviceArray (a scalar too: `ekm_hip.to_device(np.float32(85000.0))`), because
-uploads cannot be recorded; results hold no data until the first `launch()`; the graph keeps every array it touches alive
+Rules: every array operand inside the block is a DeviceArray, because uploads cannot be recorded (a Python scalar is fine:
+its value is written by a recorded fill and is a constant of the graph; a 0-d DeviceArray is a scalar that can change
+between launches); results hold no data until the first `launch()`; the graph keeps every array it touches alive
 (and their addresses fixed) until `close()`.  The reference has no counterpart: its functions run eagerly on the host."""
 import ctypes as C
 

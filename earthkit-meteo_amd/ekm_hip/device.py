@@ -148,8 +148,8 @@ def _no_capture(what):
     if _capturing() is not None:
         raise _ffi.EkmError(f"{what} inside an ekm_hip.graph() block: the block RECORDS kernel launches, nothing runs in it, so "
                             "host <-> device copies and waits have no place there -- move data with to_device / "
-                            "copy_from_host / to_host before or after the block (Python scalars and NumPy operands "
-                            "included: wrap them with ekm_hip.to_device first)")
+                            "copy_from_host / to_host before or after the block (NumPy operands included: wrap them "
+                            "with ekm_hip.to_device first; Python scalars are fine, their value is recorded)")
 
 
 class _BlockCache:
@@ -362,7 +362,7 @@ class DeviceArray:
 
     @classmethod
     def from_host(cls, array, device=None, dtype=None, capacity=0):
-        _no_capture("an upload (to_device / DeviceArray.from_host / a NumPy or scalar operand)")
+        _no_capture("an upload (to_device / DeviceArray.from_host / a NumPy operand)")
         a = np.ascontiguousarray(array, dtype=dtype)
         if a.dtype not in _DTYPES:
             a = a.astype(np.float64)

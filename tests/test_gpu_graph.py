@@ -163,3 +163,26 @@ def test_remembered_plans_give_the_first_call_s_results(dtype):
         for a, b, w in zip(*[(x if isinstance(x, tuple) else (x,)) for x in (first, again, want)]):
             assert isinstance(b, ekm_hip.DeviceArray) and np.array_equal(a.to_host(), b.to_host(), equal_nan=True)
             assert np.array_equal(b.to_host(), w, equal_nan=True)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_python_scalar_operands_are_filled_not_uploaded(dtype):
+    """A host scalar reaches the device as an asynchronous fill of its bit pattern (one word, two for fp64): eager calls
+    give the NumPy path's bits, and inside a recording the value becomes a constant of the graph."""
+    t, _, p = fields(dtype, 13)
+    dt = ekm_hip.to_device(t)
+    for value in (85000.0, dtype(50123.456), np.array(101325.0, dtype=dtype), 3):
+        want = thermo.potential_temperature(t, value)
+        got = thermo.potential_temperature(dt, value)
+        assert isinstance(got, ekm_hip.DeviceArray) and got.dtype == dtype == want.dtype
+        assert np.array_equal(got.to_host(), want, equal_nan=True), value
+    with ekm_hip.graph() as g:
+        th = thermo.potential_temperature(dt, 70000.0)
+        tt = thermo.temperature_from_potential_temperature(th, 70000.0)
+    for k in range(3):
+        tk = (t + dtype(k)).astype(dtype)
+        dt.copy_from_host(tk)
+        g.launch()
+        assert np.array_equal(th.to_host(), thermo.potential_temperature(tk, 70000.0))
+        assert np.allclose(tt.to_host(), tk, rtol=1e-5)
+    g.close()

@@ -109,8 +109,11 @@ def test_what_cannot_be_recorded_raises_before_hip(rec):
     host = np.ones(16, np.float32)
     with ekm_hip.graph() as g:
         rec.calls.clear()
-        for bad in (lambda: ekm_hip.thermo.potential_temperature(t, 85000.0),     # a Python scalar is an upload
-                    lambda: ekm_hip.thermo.potential_temperature(host, host),       # NumPy operands
+        th = ekm_hip.thermo.potential_temperature(t, 85000.0)    # a Python scalar is recorded as a fill of its bit pattern
+        assert isinstance(th, ekm_hip.DeviceArray)
+        fills = [c for c in rec.calls if c[0] == "ekm_fill_u32"]
+        assert len(fills) == 1 and fills[0][3] == int(np.float32(85000.0).view(np.uint32)) and fills[0][-1] == g.stream
+        for bad in (lambda: ekm_hip.thermo.potential_temperature(host, host),       # NumPy operands are uploads
                     lambda: t.copy_from_host(host), lambda: t.to_host(), lambda: ekm_hip.to_device(host),
                     lambda: ekm_hip.synchronize(), lambda: np.asarray(t)):
             with pytest.raises(ekm_hip.EkmError, match=r"inside an ekm_hip.graph\(\) block"):

@@ -184,6 +184,7 @@ EKM_API int ekm_h2d(int dev, void* dst, const void* src, size_t bytes, void* str
 EKM_API int ekm_d2h(int dev, void* dst, const void* src, size_t bytes, void* stream);
 EKM_API int ekm_d2d(int dev, void* dst, const void* src, size_t bytes, void* stream);
 EKM_API int ekm_memset(int dev, void* dst, int value, size_t bytes, void* stream);
+EKM_API int ekm_fill_u32(int dev, void* dst, uint32_t value, size_t count, void* stream); /* `count` 32-bit words = value (async; a scalar operand's bit pattern without a host buffer) */
 EKM_API int ekm_sync(int dev);                  /* hipDeviceSynchronize */
 EKM_API int ekm_stream_create(int dev, void** out);
 EKM_API int ekm_stream_destroy(int dev, void* stream);
