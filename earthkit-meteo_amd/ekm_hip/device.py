@@ -7,7 +7,6 @@ return DeviceArrays, so a pipeline of calls never crosses PCIe (one
 HBM time).  NumPy inputs are uploaded, computed on and downloaded per call.
 """
 import ctypes as C
-import itertools
 import math
 import os
 import threading

@@ -1,10 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic: per-level table of the hybrid-level P5 census and the details of every tw miss that the reference's own
 amplification does not explain (tests/test_gpu_census.py::test_census_p5_hybrid_levels_all_137_levels)."""
-import json
 import os
 import sys
-import time
 
 import numpy as np
 
