@@ -186,3 +186,25 @@ def test_python_scalar_operands_are_filled_not_uploaded(dtype):
         assert np.array_equal(th.to_host(), thermo.potential_temperature(tk, 70000.0))
         assert np.allclose(tt.to_host(), tk, rtol=1e-5)
     g.close()
+
+
+def test_example_recorded_forecast_steps():
+    import importlib.util
+
+    path = os.path.join(ROOT, "examples", "recorded_forecast_steps.py")
+    spec = importlib.util.spec_from_file_location("example_graph", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fields, results = mod.main(nlat=181, nlon=360, steps=5)
+    p_seen = None
+    for (t, q), res in zip(fields, results):
+        assert len(res) == 4 and all(r.shape == t.shape and r.dtype == np.float32 for r in res)
+        assert np.isfinite(res[0]).all() and (res[1] < t + 30.0).all()
+        p_seen = res
+    # the last step again through the NumPy path: the replay computed exactly that
+    # (the example's pressure is regenerated from the same seed)
+    rng = np.random.default_rng(1)
+    p = (101325.0 * (1.0 - 0.25 * rng.random((181, 360)) ** 3)).astype(np.float32)
+    want = mod.diagnostics(fields[-1][0], fields[-1][1], p)
+    for a, b in zip(p_seen, want):
+        assert np.array_equal(a, b, equal_nan=True)
