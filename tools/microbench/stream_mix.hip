@@ -40,6 +40,74 @@ __global__ __launch_bounds__(256) void mix(Ptrs in, Ptrs out, unsigned long long
   if (W == 0 && acc[0] + acc[1] + acc[2] + acc[3] == -1.2345f) *sink = acc[0];  // never true: keeps the loads alive
 }
 
+// Launch-shape variants of one mix, timed in ONE process on the SAME buffers (placement differences between processes
+// are as large as the effects looked for): NT = 256 / 512 / 1024 lanes per workgroup, TILES consecutive tiles per
+// workgroup, LD_NT / ST_NT non-temporal or plain accesses, XCD: workgroup b takes tile (b % 8) * (tiles / 8) + b / 8, so
+// that each of the eight XCDs (workgroups are dealt to them round-robin) walks one contiguous eighth of every stream.
+template <int R, int W, int NT, int TILES, bool LD_NT, bool ST_NT, bool XCD>
+__global__ __launch_bounds__(NT) void mixv(Ptrs in, Ptrs out, unsigned long long nvec) {
+  unsigned long long b = blockIdx.x;
+  if (XCD) {
+    const unsigned long long per = gridDim.x / 8;
+    if (b < per * 8) b = (b % 8) * per + b / 8;
+  }
+#pragma unroll
+  for (int k = 0; k < TILES; ++k) {
+    const unsigned long long v = (b * TILES + k) * NT + threadIdx.x;
+    if (v >= nvec) return;
+    f4 acc = {1.0f, 2.0f, 3.0f, 4.0f};
+#pragma unroll
+    for (int i = 0; i < R; ++i) acc += LD_NT ? __builtin_nontemporal_load(in.p[i] + v) : in.p[i][v];
+#pragma unroll
+    for (int o = 0; o < W; ++o) {
+      if (ST_NT)
+        __builtin_nontemporal_store(acc + (float)o, out.p[o] + v);
+      else
+        out.p[o][v] = acc + (float)o;
+    }
+  }
+}
+
+template <int R, int W, int NT, int TILES, bool LD_NT, bool ST_NT, bool XCD>
+int runv(const char* what, const Ptrs& in, const Ptrs& out, unsigned long long nvec, int reps) {
+  hipEvent_t a, b;
+  CHK(hipEventCreate(&a));
+  CHK(hipEventCreate(&b));
+  const unsigned grid = (unsigned)((nvec + (unsigned long long)NT * TILES - 1) / ((unsigned long long)NT * TILES));
+  std::vector<float> ms;
+  for (int r = 0; r < reps + 2; ++r) {
+    CHK(hipEventRecord(a, 0));
+    hipLaunchKernelGGL((mixv<R, W, NT, TILES, LD_NT, ST_NT, XCD>), dim3(grid), dim3(NT), 0, 0, in, out, nvec);
+    CHK(hipEventRecord(b, 0));
+    CHK(hipEventSynchronize(b));
+    float t;
+    CHK(hipEventElapsedTime(&t, a, b));
+    if (r >= 2) ms.push_back(t);
+  }
+  std::sort(ms.begin(), ms.end());
+  const double med = ms[ms.size() / 2], bytes = 16.0 * nvec * (R + W);
+  printf("  %d + %d  %-44s median %7.3f ms  min %7.3f ms  %7.1f GB/s\n", R, W, what, med, ms[0], bytes / med * 1e-6);
+  fflush(stdout);
+  return 0;
+}
+
+template <int R, int W>
+int variants(const Ptrs& in, const Ptrs& out, unsigned long long nvec, int reps) {
+  for (int pass = 0; pass < 2; ++pass) {  // twice: drift within the process shows as a difference between the passes
+    if (runv<R, W, 256, 1, true, true, false>("256 lanes, 1 tile, nt loads, nt stores (the map kernels)", in, out, nvec, reps)) return 1;
+    if (runv<R, W, 256, 2, true, true, false>("2 tiles per workgroup", in, out, nvec, reps)) return 1;
+    if (runv<R, W, 256, 4, true, true, false>("4 tiles per workgroup", in, out, nvec, reps)) return 1;
+    if (runv<R, W, 512, 1, true, true, false>("512 lanes", in, out, nvec, reps)) return 1;
+    if (runv<R, W, 1024, 1, true, true, false>("1024 lanes", in, out, nvec, reps)) return 1;
+    if (runv<R, W, 256, 1, false, true, false>("plain loads", in, out, nvec, reps)) return 1;
+    if (runv<R, W, 256, 1, true, false, false>("plain stores", in, out, nvec, reps)) return 1;
+    if (runv<R, W, 256, 1, false, false, false>("plain loads and stores", in, out, nvec, reps)) return 1;
+    if (runv<R, W, 256, 1, true, true, true>("XCD-contiguous tiles", in, out, nvec, reps)) return 1;
+    if (runv<R, W, 256, 4, true, true, true>("XCD-contiguous, 4 tiles per workgroup", in, out, nvec, reps)) return 1;
+  }
+  return 0;
+}
+
 template <int R, int W>
 int run(const Ptrs& in, const Ptrs& out, unsigned long long nvec, float* sink, int reps) {
   hipEvent_t a, b;
@@ -88,5 +156,11 @@ int main(int argc, char** argv) {
   if (run<2, 6>(in, out, nvec, sink, reps)) return 1;   // P5, p per level / hybrid
   if (run<0, 1>(in, out, nvec, sink, reps)) return 1;   // pressure_on_hybrid_levels
   if (run<0, 6>(in, out, nvec, sink, reps)) return 1;
+  if (argc > 2) {  // ./stream_mix reps variants
+    printf("launch-shape variants, one process, the same buffers\n");
+    if (variants<3, 6>(in, out, nvec, reps)) return 1;
+    if (variants<2, 6>(in, out, nvec, reps)) return 1;
+    if (variants<3, 3>(in, out, nvec, reps)) return 1;
+  }
   return 0;
 }
