@@ -4,7 +4,7 @@
 #   tools/bench_f64.sh <out.jsonl> [extra bench.py args...]
 OUT=${1:?out.jsonl}; shift
 : > "$OUT"
-for wl in full p3 wetbulb wetbulb_bisect theta rh ept svp; do
+for wl in full p3 wetbulb wetbulb_bisect wetbulb_bisect_bolton35 wetbulb_bisect_bolton39 theta rh ept svp; do
   timeout -k 10 150 python3 bench.py --workload $wl --dtype f64 --steps 10 --warmup 3 --no-cpu-baseline --traffic none --valu measure --sustain 0 "$@" >> "$OUT" 2>> "$OUT.err" || echo "{\"failed\": \"$wl\"}" >> "$OUT"
 done
 for pm in level hybrid; do

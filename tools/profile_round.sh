@@ -32,11 +32,12 @@ run bisect_bolton39 wetbulb_bisect_bolton39:field:f32:137 --workload wetbulb_bis
 run bisect_bolton35_f64 wetbulb_bisect_bolton35:field:f64:137 --workload wetbulb_bisect_bolton35 --dtype f64
 run full_f64        full:field:f64:137          --dtype f64
 run wetbulb_f64     wetbulb:field:f64:137       --workload wetbulb --dtype f64
-[[ valu =~ $ONLY ]] || exit 0
+finish() { mkdir -p gpurun_out/profiles_$R && cp profiles/${R}_* profiles/traffic_latest.json profiles/valu_latest.json gpurun_out/profiles_$R/; }
+[[ valu =~ $ONLY ]] || { finish; exit 0; }
 for wl in full wetbulb wetbulb_bisect wetbulb_bisect_bolton35 wetbulb_bisect_bolton39 p3; do
   tools/profile_valu.sh "$G/valu_$wl" --workload $wl > "$G/valu_$wl.log" 2>&1 && python3 tools/summarize_valu.py "$G/valu_$wl" $wl "profiles/${R}_valu_counters.json"
 done
 for wl in wetbulb wetbulb_bisect; do
   tools/profile_valu.sh "$G/valu_${wl}_level" --workload $wl --pmode level > /dev/null 2>&1 && python3 tools/summarize_valu.py "$G/valu_${wl}_level" ${wl}@level "profiles/${R}_valu_counters.json"
 done
-mkdir -p gpurun_out/profiles_$R && cp profiles/${R}_* profiles/traffic_latest.json profiles/valu_latest.json gpurun_out/profiles_$R/
+finish
