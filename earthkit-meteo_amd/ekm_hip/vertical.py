@@ -359,8 +359,8 @@ class HybridPressure:
     pressure field is never read from (or written to) HBM."""
 
     def __init__(self, A, B, sp):
-        self.A = np.ascontiguousarray(A, dtype=np.float64)
-        self.B = np.ascontiguousarray(B, dtype=np.float64)
+        self.A = np.array(A, dtype=np.float64, order="C")  # copies: the device tables made from them are kept (device_tables)
+        self.B = np.array(B, dtype=np.float64, order="C")
         if self.A.ndim != 1 or self.A.shape != self.B.shape or self.A.size < 2:
             raise ValueError("A and B must be 1-D half-level tables of the same length >= 2")
         self.sp = sp
