@@ -263,7 +263,7 @@ def plan_shard(workload, pmode, scaling, rank, world, nlev=NLEV, inner=INNER):
         the horizontal axis, each rank holding [nlev, its columns].
     Returns first (flat index of the shard's first point in the global field; column shards: first column),
     n_local, n_total, lev0/lev1 (level range), col0/col1 (column range)."""
-    from ekm_hip._engine import leading_axis_bounds
+    from ekm_hip._streamed import leading_axis_bounds
     from ekm_hip.device import shard_bounds
 
     n_field = nlev * inner

@@ -33,5 +33,5 @@ from .device import (  # noqa: F401
 __version__ = "0.1.0"
 from .vertical import HybridPressure  # noqa: F401,E402
 from .dlpack import from_dlpack  # noqa: F401,E402
-from ._engine import release_streams  # noqa: F401,E402
+from ._streamed import release_streams  # noqa: F401,E402
 from ._graph import Graph, graph  # noqa: F401,E402

@@ -3,7 +3,7 @@ kernels as a field / scalar / level vector), dtype promotion, sharding, error co
 import numpy as np
 import pytest
 
-from ekm_hip import _engine, _ffi
+from ekm_hip import _engine, _ffi, _streamed
 from ekm_hip.device import shard_bounds
 
 F, S, MAJ, MIN = _ffi.FIELD, _ffi.SCALAR, _ffi.LEVEL_MAJOR, _ffi.LEVEL_MINOR
@@ -105,7 +105,7 @@ def test_signatures_match_the_reference():
 
 @pytest.mark.parametrize("n0,k", [(137, 8), (137, 1), (721, 4), (8, 8), (9, 8), (3, 2)])
 def test_leading_axis_bounds(n0, k):
-    b = _engine.leading_axis_bounds(n0, k)
+    b = _streamed.leading_axis_bounds(n0, k)
     assert len(b) == k and b[0][0] == 0 and b[-1][1] == n0
     assert all(hi == lo2 for (_, hi), (lo2, _) in zip(b, b[1:]))
     sizes = [hi - lo for lo, hi in b]

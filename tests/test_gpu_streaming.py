@@ -41,7 +41,7 @@ def test_large_multi_output_numpy_call_is_bit_equal_to_the_device_path(ek):
 def test_converted_operands_share_the_slice_pipeline(ek):
     """float64 inputs with a float32 override are converted copies: they travel with the other operands of a slice, rows
     of 8 MiB + 4112 B put the slice boundaries off the page grid, and the results are the bits of the device path."""
-    from ekm_hip import _engine
+    from ekm_hip import _engine, _streamed  # noqa: F401
 
     t, q, p = _fields(16, (1 << 21) + 1028)
     want = _device_path(ek, "pipeline_svp_td_rh", (t, q, p))
@@ -49,7 +49,7 @@ def test_converted_operands_share_the_slice_pipeline(ek):
         got = ek.thermo.pipeline_svp_td_rh(t, q, p)
         for k, (g, w) in enumerate(zip(got, want)):
             assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), f"rep {rep} output {k} differs"
-    got64 = _engine._run_streamed("potential_temperature", (t.astype(np.float64), p), (), None, np.float32, [ek.current_device()])[0]
+    got64 = _streamed._run_streamed("potential_temperature", (t.astype(np.float64), p), (), None, np.float32, [ek.current_device()])[0]
     assert np.array_equal(got64, _device_path(ek, "potential_temperature", (t, p))[0])
 
 
@@ -96,7 +96,7 @@ def test_streaming_stays_within_a_capped_device_budget(ek, monkeypatch):
     """fields whose working set exceeds the device budget stream through in slices, two or
     more in flight, device blocks recycled between slices.  Budget capped at 96 MiB against a 768 MiB
     working set; the peak of live device bytes must stay under the cap and the result must be unchanged."""
-    from ekm_hip import _engine
+    from ekm_hip import _engine, _streamed  # noqa: F401
 
     t, q, p = _fields(64, 1 << 19)  # 3 x 128 MiB in, 3 x 128 MiB out = 768 MiB working set
     want = _device_path(ek, "pipeline_svp_td_rh", (t, q, p))
@@ -105,7 +105,7 @@ def test_streaming_stays_within_a_capped_device_budget(ek, monkeypatch):
     ek.empty_cache()
     ek.memory_stats(reset_peak=True)
     base = ek.memory_stats()["live_bytes"]
-    lanes, nslices = _engine.plan_slices(64, 6 * (1 << 19) * 4, cap, overhead=6 * _engine._BLOCK_OVERHEAD)
+    lanes, nslices = _streamed.plan_slices(64, 6 * (1 << 19) * 4, cap, overhead=6 * _streamed._BLOCK_OVERHEAD)
     assert lanes >= 2 and nslices > lanes  # more slices than lanes: blocks are recycled
     got = ek.thermo.pipeline_svp_td_rh(t, q, p)
     st = ek.memory_stats()
@@ -130,9 +130,9 @@ def test_level_vector_operand_is_sliced_with_the_fields(ek):
     pfull = np.ascontiguousarray(np.broadcast_to(plev, t.shape))
     want = _device_path(ek, "potential_temperature", (t, pfull))[0]
     got = ek.thermo.potential_temperature(t, plev)  # 2 x 128 MiB... t alone is 128 MiB: force the streamed path
-    from ekm_hip import _engine
+    from ekm_hip import _engine, _streamed  # noqa: F401
 
-    got2 = _engine._run_streamed("potential_temperature", (t, plev), (), None, None, [ek.current_device()])[0]
+    got2 = _streamed._run_streamed("potential_temperature", (t, plev), (), None, None, [ek.current_device()])[0]
     assert np.array_equal(got, want) and np.array_equal(got2, want)
 
 
@@ -143,10 +143,10 @@ def test_float16_and_dtype_override_do_not_depend_on_size(ek):
     for a in (small, big):
         out = ek.thermo.saturation_vapour_pressure(a)
         assert out.dtype == np.float16, (a.size, out.dtype)
-    from ekm_hip import _engine
+    from ekm_hip import _engine, _streamed  # noqa: F401
 
     t, q, p = _fields(8, 1 << 16)
-    o = _engine._run_streamed("potential_temperature", (t, p), (), None, np.float64, [ek.current_device()])[0]
+    o = _streamed._run_streamed("potential_temperature", (t, p), (), None, np.float64, [ek.current_device()])[0]
     assert o.dtype == np.float64
 
 
@@ -216,14 +216,14 @@ def test_scalar_pressure_with_ragged_length_takes_the_vector_path(ek):
 
 
 def test_lane_streams_are_bounded_and_releasable(ek):
-    from ekm_hip import _engine
+    from ekm_hip import _engine, _streamed  # noqa: F401
 
     t, q, p = _fields(24, 1 << 18)
     for rows in (24, 17, 9):  # different leading-axis lengths must not create new streams per length
-        _engine._run_streamed("potential_temperature", (t[:rows], p[:rows]), (), None, None, [ek.current_device()])
-    assert 0 < len(_engine._streams) <= _engine._MAX_LANES
+        _streamed._run_streamed("potential_temperature", (t[:rows], p[:rows]), (), None, None, [ek.current_device()])
+    assert 0 < len(_streamed._streams) <= _streamed._MAX_LANES
     ek.release_streams()
-    assert len(_engine._streams) == 0
+    assert len(_streamed._streams) == 0
     out = ek.thermo.potential_temperature(t, p)  # still works afterwards (streams are re-created on demand)
     assert np.isfinite(out).all()
 

@@ -1,7 +1,7 @@
-"""Slice planning of the streamed NumPy path (ekm_hip._engine.plan_slices) -- host logic, no GPU."""
+"""Slice planning of the streamed NumPy path (ekm_hip._streamed.plan_slices) -- host logic, no GPU."""
 import pytest
 
-from ekm_hip._engine import leading_axis_bounds, plan_slices
+from ekm_hip._streamed import leading_axis_bounds, plan_slices
 
 MiB = 1 << 20
 
