@@ -298,13 +298,15 @@ def _run(name, args, ints, eps, dtype):
 # staged through a ring of pinned buffers (44-57 GB/s in the pipeline), the caller's memory pinned in place slice by slice
 # (31-44), both together (43-54) -- and removed in round 4: none came near the default.
 # Pinned memory is page-locked: it cannot be swapped and counts against container and memlock limits.  So the pool is
-# bounded -- a call's results go there only up to EKM_PINNED_RESULTS_BYTES (default 4 GiB per call), callers may hold
-# at most EKM_PINNED_LIVE_BYTES (4 GiB) of such results alive at once and at most EKM_PINNED_CACHE_BYTES (1 GiB) stay
-# cached after they are dropped; beyond that results are ordinary arrays (prefaulted from a helper thread).  A result in
-# pooled memory does not own its data (`.base` is a ctypes buffer; `ndarray.resize` refuses): EKM_PINNED_RESULTS=0 turns
-# the pool off.
+# bounded -- at most EKM_PINNED_CACHE_BYTES (2 GiB) of dropped result blocks stay cached, callers may hold at most
+# EKM_PINNED_LIVE_BYTES (4 GiB) of such results alive at once, and a call's results go there only if the pool would keep
+# them afterwards (EKM_PINNED_RESULTS_BYTES, default = the cache limit): blocks the pool cannot keep are pinned anew by
+# every call, and pinning is slow -- with a 1-GiB cache the 2.5 GB of results of a 32-level P3 call took 401 ms per call
+# from the pool against 82 ms as ordinary arrays (profiles/r04_host_path_rate.txt).  Beyond the limits results are
+# ordinary arrays, prefaulted from a helper thread.  A result in pooled memory does not own its data (`.base` is a ctypes
+# buffer; `ndarray.resize` refuses): EKM_PINNED_RESULTS=0 turns the pool off.
 _PINNED_OUT = os.environ.get("EKM_PINNED_RESULTS", "1") != "0"
-_PINNED_OUT_BYTES = int(os.environ.get("EKM_PINNED_RESULTS_BYTES", str(4 << 30)))
+_PINNED_OUT_BYTES = int(os.environ.get("EKM_PINNED_RESULTS_BYTES", os.environ.get("EKM_PINNED_CACHE_BYTES", str(2 << 30))))
 
 
 class _Pending:

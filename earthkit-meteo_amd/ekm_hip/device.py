@@ -503,19 +503,20 @@ class _PinnedPool:
     through a finalizer, and when the caller drops the array (and every view of it) the block comes back here.
     Page-locked memory cannot be swapped and counts against container / memlock limits, so the pool is small by
     default: once the callers hold EKM_PINNED_LIVE_BYTES (default 4 GiB) of pinned results alive, further results are
-    ordinary pageable arrays, and at most EKM_PINNED_CACHE_BYTES (default 1 GiB) of dropped blocks stay cached, the rest
+    ordinary pageable arrays, and at most EKM_PINNED_CACHE_BYTES (default 2 GiB) of dropped blocks stay cached, the rest
     is freed at once (`ekm_hip.empty_cache()` frees the cached ones too).  An array in pooled memory does not own its
     data: `.base` is a ctypes buffer and `ndarray.resize` refuses."""
 
     def __init__(self):
         self.free = {}    # bucket -> [ptr, ...]
         self.cached = 0
-        self.limit = int(os.environ.get("EKM_PINNED_CACHE_BYTES", str(1 << 30)))
+        self.limit = int(os.environ.get("EKM_PINNED_CACHE_BYTES", str(2 << 30)))
         self.live_limit = int(os.environ.get("EKM_PINNED_LIVE_BYTES", str(4 << 30)))  # pinned bytes callers may hold at once
         # re-entrant: give() runs from a weakref finalizer, which the cyclic garbage collector may fire at any allocation
         # inside take() / give() / drain() of the very thread that holds the lock
         self.lock = threading.RLock()
         self.handed_out = 0
+        self.tick, self.used = 0, {}  # bucket -> when a block of that size last came or went
 
     @staticmethod
     def bucket(nbytes):
@@ -528,6 +529,8 @@ class _PinnedPool:
             if self.handed_out + b > self.live_limit:
                 return None, b  # the caller keeps many results alive: further ones are ordinary pageable arrays
             self.handed_out += b  # reserved under the lock, before the (slow) allocation: the limit cannot be overshot
+            self.tick += 1
+            self.used[b] = self.tick
             lst = self.free.get(b)
             if lst:
                 self.cached -= b
@@ -540,14 +543,28 @@ class _PinnedPool:
         return out.value, b
 
     def give(self, ptr, b):
+        """A block comes back.  It is cached if the limit allows -- making room, if need be, by letting go of blocks of the
+        sizes that have gone unused the longest (a workload that changes its field size must not be stuck with a cache full
+        of the old size, pinning its new blocks anew at every call)."""
+        evicted = []
         with self.lock:
             self.handed_out -= b
-            if self.cached + b <= self.limit:
-                self.free.setdefault(b, []).append(ptr)
-                self.cached += b
-                return
+            self.tick += 1
+            self.used[b] = self.tick
+            if b <= self.limit:
+                while self.cached + b > self.limit:
+                    old = min((k for k, lst in self.free.items() if lst and k != b), key=lambda k: self.used.get(k, 0), default=None)
+                    if old is None:
+                        break
+                    evicted.append(self.free[old].pop())
+                    self.cached -= old
+                if self.cached + b <= self.limit:
+                    self.free.setdefault(b, []).append(ptr)
+                    self.cached += b
+                    ptr = None
         try:
-            _ffi.lib().ekm_host_free(ptr)
+            for p in evicted + ([ptr] if ptr else []):
+                _ffi.lib().ekm_host_free(p)
         except Exception:  # interpreter shutdown
             pass
 

@@ -32,7 +32,7 @@ class Recorder:
             self.calls.append((name,) + plain)
             self.operands.append([(o._obj.data, o._obj.mode, o._obj.len, o._obj.inner) for o in args
                                   if hasattr(o, "_obj") and isinstance(o._obj, _ffi.Operand)])
-            if name in ("ekm_stream_create", "ekm_event_create", "ekm_malloc"):
+            if name in ("ekm_stream_create", "ekm_event_create", "ekm_malloc", "ekm_host_alloc"):
                 args[-1]._obj.value = self._handle()
             if name == "ekm_graph_end":
                 if self.fail_end:
@@ -201,3 +201,30 @@ def test_a_device_resident_call_is_planned_once_and_launched_from_the_recipe(rec
     monkeypatch.setattr(device._tls, "devices", (0, 1), raising=False)   # as inside ekm_hip.multi_gpu([0, 1])
     with pytest.raises(ekm_hip.EkmError, match="multi_gpu"):
         ekm_hip.thermo.potential_temperature(t, one)            # remembered, but sharding goes the general way (and refuses)
+
+
+def test_pinned_pool_lets_go_of_the_sizes_that_went_unused_longest(rec, monkeypatch):
+    """device._PinnedPool: a cache full of one block size must not keep a workload with a new field size from caching its
+    blocks (every call would pin them anew): the oldest-unused sizes are evicted to make room, within the byte limit."""
+    pool = device._PinnedPool()
+    pool.limit, pool.live_limit = 8 << 20, 64 << 20
+    rec.calls.clear()
+    small = [pool.take(2 << 20) for _ in range(4)]              # four 2-MiB blocks: allocated
+    assert [c[0] for c in rec.calls] == ["ekm_host_alloc"] * 4
+    for ptr, b in small:
+        pool.give(ptr, b)
+    assert pool.cached == 8 << 20 and pool.handed_out == 0      # all four cached: the cache is full
+    rec.calls.clear()
+    big, bb = pool.take(6 << 20)                                # a new size: allocated ...
+    pool.give(big, bb)                                          # ... and cached, three of the old blocks let go
+    assert [c[0] for c in rec.calls] == ["ekm_host_alloc", "ekm_host_free", "ekm_host_free", "ekm_host_free"]
+    assert pool.cached == (6 << 20) + (2 << 20)
+    rec.calls.clear()
+    again, _ = pool.take(6 << 20)                               # recycled: no allocation
+    assert again == big and rec.calls == []
+    pool.give(again, bb)
+    huge, hb = pool.take(16 << 20)                              # larger than the whole cache: never cached
+    pool.give(huge, hb)
+    assert pool.cached == 8 << 20 and rec.calls[-1][0] == "ekm_host_free"
+    pool.drain()
+    assert pool.cached == 0
