@@ -1,6 +1,8 @@
-"""ekm_hip.graph() host logic without a GPU: the order of the runtime calls, which blocks a recording pins and when it
-lets go of them, and that everything that cannot be recorded raises before HIP is reached.  The library is replaced by a
-recorder (tests/test_gpu_graph.py runs the real thing)."""
+"""Host logic that needs no GPU, with a RECORDER in place of libekm_thermo.so (every call logged, handles from a counter):
+ * ekm_hip.graph(): the order of the runtime calls, which blocks a recording pins and when it lets go of them, and that
+   everything that cannot be recorded raises before HIP is reached (tests/test_gpu_graph.py runs the real thing);
+ * remembered plans: a device-resident call is planned once and repeats hand the library identical arguments;
+ * the pinned result pool's eviction rule."""
 import ctypes as C
 import os
 import sys
