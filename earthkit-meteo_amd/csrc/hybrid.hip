@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kThreads) void hybrid_levels(const T* __restrict__ 
   const bool whole = vec_ok && (i0 + V <= npts);
   Vec s;
   if (whole) {
-    s = *reinterpret_cast<const Vec*>(sp + i0);
+    s = ld_cached<T>(sp + i0);
   } else {
 #pragma unroll
     for (int j = 0; j < V; ++j) s[j] = (i0 + j < npts) ? sp[i0 + j] : T(1);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kThreads) void hybrid_rows(const T* __restrict__ A,
   const bool whole = vec_ok && (i0 + V <= npts);
   Vec s;
   if (whole) {
-    s = *reinterpret_cast<const Vec*>(sp + i0);  // cached: the other levels of the band re-read it
+    s = ld_cached<T>(sp + i0);  // cached: the other levels of the band re-read it
   } else {
 #pragma unroll
     for (int j = 0; j < V; ++j) s[j] = (i0 + j < npts) ? sp[i0 + j] : T(1);
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kGeoThreads) void geopotential_columns(const T* __r
   if (k_hi < nfull) {  // not the bottom chunk: pick up the running sum left in our first output row
     const T* src = out + (unsigned long long)(k_hi - 1) * npts + i0;
     if (VEC) {
-      acc = *reinterpret_cast<const Vec*>(src);
+      acc = ld_cached<T>(src);
     } else {
 #pragma unroll
       for (int j = 0; j < V; ++j) acc[j] = (i0 + j < npts) ? src[j] : T(0);
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(kGeoThreads) void geopotential_columns(const T* __r
   if (k_lo > 0) {  // hand the running sum to the chunk above
     T* dst = out + (unsigned long long)(k_lo - 1) * npts + i0;
     if (VEC) {
-      *reinterpret_cast<Vec*>(dst) = acc;
+      st_cached<T>(dst, acc);
     } else {
 #pragma unroll
       for (int j = 0; j < V; ++j)
@@ -348,7 +348,7 @@ static int launch_geopotential(int dev, void* stream, const T* A, const T* B, co
   int vec_ok = (npts % V == 0);
   for (const void* ptr : {(const void*)sp, (const void*)zs, (const void*)t, (const void*)q, (const void*)out,
                           (const void*)alpha_in, (const void*)delta_in})
-    if (ptr && reinterpret_cast<uintptr_t>(ptr) % 16) vec_ok = 0;
+    if (ptr && reinterpret_cast<uintptr_t>(ptr) % sizeof(T)) vec_ok = 0;
   const unsigned long long nchunk = (npts + V - 1) / V;
   const unsigned long long grid = (nchunk + kGeoThreads - 1) / kGeoThreads;
   if (grid > 0x7fffffffull) return set_error(EKM_ERR_ARG, "geopotential_on_hybrid_levels: too many columns");
@@ -386,9 +386,9 @@ static int launch_hybrid(int dev, void* stream, const T* A, const T* B, const T*
   int rc = use_device(dev);
   if (rc != EKM_OK) return rc;
   constexpr int V = VecOf<T>::N;
-  int vec_ok = (npts % V == 0) && reinterpret_cast<uintptr_t>(sp) % 16 == 0;
+  int vec_ok = (npts % V == 0) && reinterpret_cast<uintptr_t>(sp) % sizeof(T) == 0;
   for (T* o : {full, half, delta, alpha})
-    if (o && reinterpret_cast<uintptr_t>(o) % 16) vec_ok = 0;
+    if (o && reinterpret_cast<uintptr_t>(o) % sizeof(T)) vec_ok = 0;
   const unsigned long long nchunk = (npts + V - 1) / V;
   const unsigned long long grid = (nchunk + kThreads - 1) / kThreads;
   if (grid > 0x7fffffffull) return set_error(EKM_ERR_ARG, "pressure_on_hybrid_levels: too many columns");

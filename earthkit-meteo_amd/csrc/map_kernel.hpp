@@ -48,13 +48,28 @@ struct VecOf;
 template <>
 struct VecOf<float> {
   typedef float type __attribute__((ext_vector_type(4)));
+  typedef float mem_type __attribute__((ext_vector_type(4), aligned(4)));
   static constexpr int N = 4;
 };
 template <>
 struct VecOf<double> {
   typedef double type __attribute__((ext_vector_type(2)));
+  typedef double mem_type __attribute__((ext_vector_type(2), aligned(8)));
   static constexpr int N = 2;
 };
+// `mem_type`: the 16-B vector as it is loaded from and stored to global memory -- declared with the ELEMENT's alignment.
+// gfx950 runs global memory in unaligned-access mode (the compiler itself emits global_load_dwordx4 for a 4-B-aligned
+// vector), so a field whose pointer is not 16-B aligned -- a view at an odd offset, another library's tensor slice --
+// takes the same instructions and kernels as an aligned one (it fell to one dword per access before: 0.5-0.6 of the rate,
+// profiles/r04_odd_shapes.txt).
+template <class T>
+__device__ __forceinline__ typename VecOf<T>::type ld_cached(const T* p) {
+  return *reinterpret_cast<const typename VecOf<T>::mem_type*>(p);
+}
+template <class T>
+__device__ __forceinline__ void st_cached(T* p, typename VecOf<T>::type v) {
+  *reinterpret_cast<typename VecOf<T>::mem_type*>(p) = v;
+}
 
 template <class T, int NIN, int NOUT>
 struct MapArgs {
@@ -69,7 +84,7 @@ struct MapArgs {
   unsigned long long inner[NIN]; // LEVEL_MAJOR: points per level
   unsigned long long step_q[NIN];  // (elements per tile) / inner   resp. unused
   unsigned long long step_r[NIN];  // (elements per tile) % inner   resp. % len
-  int vec_ok;                    // all field pointers 16-B aligned
+  int vec_ok;                    // all field pointers element-aligned (always, for arrays of T)
   int switches;                  // test / A-B switches: bit 0 fp64: redo every lane in plain double (tuning parameter f64_plain);
                                  // bit 1 fp32 IFS bisection: the exact residual at every step (bisect_exact)
   const T* aux0;                 // EKM_HYBRID_FULL (last operand): A half-level table
@@ -85,7 +100,7 @@ struct MapArgs {
 
 template <class T>
 __device__ __forceinline__ typename VecOf<T>::type ld_stream(const T* p) {
-  typedef typename VecOf<T>::type V;
+  typedef typename VecOf<T>::mem_type V;
 #if EKM_NT_LOAD
   return __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
 #else
@@ -95,7 +110,7 @@ __device__ __forceinline__ typename VecOf<T>::type ld_stream(const T* p) {
 
 template <class T>
 __device__ __forceinline__ void st_stream(T* p, typename VecOf<T>::type v) {
-  typedef typename VecOf<T>::type V;
+  typedef typename VecOf<T>::mem_type V;
 #if EKM_NT_STORE
   __builtin_nontemporal_store(v, reinterpret_cast<V*>(p));
 #else
@@ -495,7 +510,7 @@ __global__ __launch_bounds__((OpThreads<Op, T>::value), (OpThreads<Op, T>::tree 
     if (PMODE == PM_HYBRID || PMODE == PM_FLAT) {
       const T* sp = a.in[PI];
       if (ALIGNED && col + V <= a.inner) {
-        const Vec sv = *reinterpret_cast<const Vec*>(sp + col);  // cached load: other level groups re-read it
+        const Vec sv = ld_cached<T>(sp + col);  // cached load: other level groups re-read it
 #pragma unroll
         for (int j = 0; j < V; ++j) s[j] = sv[j];
       } else {
@@ -742,7 +757,7 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
     a.step_q[i] = a.step_r[i] = 0;
     switch (op->mode) {
       case EKM_FIELD:
-        if (reinterpret_cast<uintptr_t>(op->data) % 16) aligned = false;
+        if (reinterpret_cast<uintptr_t>(op->data) % sizeof(T)) aligned = false;
         break;
       case EKM_SCALAR:
         bc = true;
@@ -778,7 +793,7 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
         if (op->len == 0 || op->len > 8000u || op->inner < (unsigned)V || (unsigned long long)op->len * op->inner < n)
           return set_error(EKM_ERR_ARG, "operand %d: EKM_HYBRID_FULL needs 0 < len <= 8000, inner >= %d, len*inner >= n", i,
                            V);
-        if (reinterpret_cast<uintptr_t>(op->data) % 16) aligned = false;
+        if (reinterpret_cast<uintptr_t>(op->data) % sizeof(T)) aligned = false;
         a.len[i] = (unsigned)op->len;
         a.inner[i] = op->inner;
         a.aux0 = static_cast<const T*>(op->aux0);
@@ -792,7 +807,7 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
   for (int o = 0; o < NOUT; ++o) {
     if (!outs[o]) return set_error(EKM_ERR_ARG, "output %d: null pointer", o);
     a.out[o] = static_cast<T*>(outs[o]);
-    if (reinterpret_cast<uintptr_t>(outs[o]) % 16) aligned = false;
+    if (reinterpret_cast<uintptr_t>(outs[o]) % sizeof(T)) aligned = false;
   }
   a.vec_ok = aligned ? 1 : 0;
   // staged level vectors: at most 32 KiB of dynamic LDS (what the host layer hands over at most); the op's own

@@ -308,6 +308,34 @@ def test_unaligned_device_views(ek, orc):
         assert_parity(got, orc.potential_temperature(t[off:], p[off:]), "f32", f"offset {off}")
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_unaligned_views_give_the_aligned_results_bit_for_bit(ek, dt):
+    """Fields whose pointers are only element-aligned (a view at an odd offset) run the same 16-B-per-lane kernels as
+    16-B-aligned ones (gfx950 accesses global memory in unaligned mode; map_kernel.hpp::VecOf::mem_type): the six-output
+    pipeline, the LDS-tree bisection, a level-vector call and the column kernels, against the same data copied to aligned
+    arrays."""
+    from oracle import synthetic
+
+    nlev, npts = 6, 4100
+    t, q, p, _ = synthetic.make_fields(nlev, npts, dtype=dt, seed=33)
+    n = nlev * npts
+    lev = np.ascontiguousarray(p.reshape(nlev, npts)[:, :1])
+    for off in (1, 3):
+        pad = np.zeros(off, dt)
+        big = [ek.to_device(np.concatenate([pad, a.ravel()])) for a in (t, q, p)]
+        ut, uq, up = (b.flat_slice(off, off + n) for b in big)                       # unaligned views
+        at, aq, ap = (ek.to_device(a.ravel()) for a in (t, q, p))                     # aligned copies
+        assert ut.ptr % 16 != 0 and at.ptr % 16 == 0
+        pairs = [(ek.thermo.pipeline_full(ut, uq, up), ek.thermo.pipeline_full(at, aq, ap)),
+                 ((ek.thermo.wet_bulb_temperature_from_specific_humidity(ut, uq, up),),
+                  (ek.thermo.wet_bulb_temperature_from_specific_humidity(at, aq, ap),)),
+                 ((ek.thermo.relative_humidity_from_specific_humidity(ut.reshape(nlev, npts), uq.reshape(nlev, npts), lev),),
+                  (ek.thermo.relative_humidity_from_specific_humidity(at.reshape(nlev, npts), aq.reshape(nlev, npts), lev),))]
+        for got, want in pairs:
+            for g, w in zip(got, want):
+                assert np.array_equal(g.to_host().ravel(), w.to_host().ravel(), equal_nan=True), off
+
+
 def test_device_resident_chain(ek, orc, slab):
     t, q, p = (slab["f32"][k] for k in ("t", "q", "p"))
     dt, dq, dp = (ek.to_device(a) for a in (t, q, p))
