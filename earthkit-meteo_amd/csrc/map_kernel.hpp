@@ -901,9 +901,9 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
           if (band > ntx) band = ntx;
           while ((ntx + band - 1) / band > 65535ull) band *= 2;
         }
-        // rows start 16-B aligned when the row length is a multiple of the vector width -- or when there is only one
-        // row (a scalar operand with any n): its ragged end is handled by the kernel's own `col + V <= rowlen` test
-        const bool al = aligned && (inner % V == 0 || nlev == 1);
+        // A row need not start 16-B aligned (VecOf::mem_type: element alignment is enough), so rows of any length take the
+        // vector path; the ragged end of a row is handled by the kernel's own `col + V <= rowlen` test
+        const bool al = aligned;
         // one launch over the levels [k_lo, k_hi) of the call: pointers, tables and counts rebased to k_lo
         auto launch_part = [&](int pmode, unsigned k_lo, unsigned k_hi, unsigned walk) {
           LevArgs<T, NIN, NOUT> q = la;

@@ -49,6 +49,7 @@ def main():
         ("fields, n not a multiple of 4", lambda: thermo.potential_temperature(f3(t, 0, n - 3), f3(p, 0, n - 3)), n - 3, 12),
         ("p a level vector (137,1,1)-style", lambda: thermo.potential_temperature(f3(t).reshape(nlev, nlat, nlon), lev.reshape(nlev, 1, 1)), n, 8),
         ("p a level vector, field 4 B off alignment", lambda: thermo.potential_temperature(f3(t, 1).reshape(nlev, nlat, nlon), lev.reshape(nlev, 1, 1)), n, 8),
+        ("p a level vector, rows of odd length (1799 x 3601)", lambda: thermo.potential_temperature(f3(t, 0, nlev * 1799 * 3601).reshape(nlev, 1799, 3601), lev.reshape(nlev, 1, 1)), nlev * 1799 * 3601, 8),
         ("p a scalar (0-d DeviceArray)", lambda: thermo.potential_temperature(f3(t), ekm_hip.to_device(np.float32(85000.0))), n, 8),
         ("p along the trailing axis (nlon,)", lambda: thermo.potential_temperature(f3(t).reshape(nlev, nlat, nlon), lon), n, 8),
         ("t a level vector, p a field", lambda: thermo.potential_temperature(lev.reshape(nlev, 1, 1), f3(p).reshape(nlev, nlat, nlon)), n, 8),
