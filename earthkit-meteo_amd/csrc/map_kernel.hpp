@@ -84,7 +84,7 @@ struct MapArgs {
   unsigned long long inner[NIN]; // LEVEL_MAJOR: points per level
   unsigned long long step_q[NIN];  // (elements per tile) / inner   resp. unused
   unsigned long long step_r[NIN];  // (elements per tile) % inner   resp. % len
-  int vec_ok;                    // all field pointers element-aligned (always, for arrays of T)
+  int vec_ok;                    // always 1 since round 4 (element-aligned pointers are enough for the 16-B accesses)
   int switches;                  // test / A-B switches: bit 0 fp64: redo every lane in plain double (tuning parameter f64_plain);
                                  // bit 1 fp32 IFS bisection: the exact residual at every step (bisect_exact)
   const T* aux0;                 // EKM_HYBRID_FULL (last operand): A half-level table
@@ -318,7 +318,7 @@ __global__ __launch_bounds__((OpThreads<Op, T>::value), (OpThreads<Op, T>::field
   }
 }
 
-// ---- some operands are scalars / level vectors (or pointers are unaligned) ---
+// ---- some operands are scalars / level vectors in a general position ---
 extern __shared__ __align__(16) unsigned char ekm_lds_raw[];
 
 template <class Op, class T>
@@ -491,7 +491,7 @@ struct LevArgs {
 // whose surface pressure is not finite (never in real data) are redone point by point with that NaN.
 // WALK (PM_HYBRID only): the workgroup walks `lev_per_wg` > 1 consecutive levels of its tile with sp and the shared
 // half-level pressure in registers.
-template <class Op, class T, int PMODE, bool ALIGNED, bool WALK = false>
+template <class Op, class T, int PMODE, bool WALK = false>
 __global__ __launch_bounds__((OpThreads<Op, T>::value), (OpThreads<Op, T>::tree ? OpThreads<Op, T>::field_waves : sizeof(T) == 4 ? OpWaves<Op>::value : EKM_WAVES_PER_EU)) void map_levels(const LevArgs<T, Op::NIN, Op::NOUT> a) {
   constexpr int NIN = Op::NIN, NOUT = Op::NOUT, V = VecOf<T>::N, PI = Op::NIN - 1, NT = OpThreads<Op, T>::value;
   typedef typename VecOf<T>::type Vec;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__((OpThreads<Op, T>::value), (OpThreads<Op, T>::tree 
     bool sp_ok = true;  // PM_FLAT: this lane's surface pressures are all finite
     if (PMODE == PM_HYBRID || PMODE == PM_FLAT) {
       const T* sp = a.in[PI];
-      if (ALIGNED && col + V <= a.inner) {
+      if (col + V <= a.inner) {
         const Vec sv = ld_cached<T>(sp + col);  // cached load: other level groups re-read it
 #pragma unroll
         for (int j = 0; j < V; ++j) s[j] = sv[j];
@@ -561,7 +561,7 @@ __global__ __launch_bounds__((OpThreads<Op, T>::value), (OpThreads<Op, T>::tree 
         }
       };
       auto run_level = [&](auto pressure) {
-        if (ALIGNED && col + V <= rowlen) {
+        if (col + V <= rowlen) {
           Vec xin[NIN > 1 ? NIN - 1 : 1], yout[NOUT];
 #pragma unroll
           for (int f = 0; f < PI; ++f) xin[f] = ld_stream<T>(a.in[f] + e0);
@@ -580,7 +580,7 @@ __global__ __launch_bounds__((OpThreads<Op, T>::value), (OpThreads<Op, T>::tree 
           }
 #pragma unroll
           for (int o = 0; o < NOUT; ++o) st_stream<T>(a.out[o] + e0, yout[o]);
-        } else {  // unaligned rows / ragged end of a row
+        } else {  // ragged end of a row
           run_points(pressure, [](int) { return true; });
         }
       };
@@ -809,7 +809,8 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
     a.out[o] = static_cast<T*>(outs[o]);
     if (reinterpret_cast<uintptr_t>(outs[o]) % sizeof(T)) aligned = false;
   }
-  a.vec_ok = aligned ? 1 : 0;
+  if (!aligned) return set_error(EKM_ERR_ARG, "a field pointer is not aligned to its element size (%d B)", (int)sizeof(T));
+  a.vec_ok = 1;
   // staged level vectors: at most 32 KiB of dynamic LDS (what the host layer hands over at most); the op's own
   // per-workgroup table is static LDS on top of that (the CU has 160 KiB)
   if ((size_t)lds_elems * sizeof(T) > kMaxLdsBytes)
@@ -901,9 +902,8 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
           if (band > ntx) band = ntx;
           while ((ntx + band - 1) / band > 65535ull) band *= 2;
         }
-        // A row need not start 16-B aligned (VecOf::mem_type: element alignment is enough), so rows of any length take the
-        // vector path; the ragged end of a row is handled by the kernel's own `col + V <= rowlen` test
-        const bool al = aligned;
+        // (A row need not start 16-B aligned -- VecOf::mem_type: element alignment is enough --, so rows of any length take
+        // the vector path; the ragged end of a row is handled by the kernel's own `col + V <= rowlen` test.)
         // one launch over the levels [k_lo, k_hi) of the call: pointers, tables and counts rebased to k_lo
         auto launch_part = [&](int pmode, unsigned k_lo, unsigned k_hi, unsigned walk) {
           LevArgs<T, NIN, NOUT> q = la;
@@ -923,17 +923,15 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
           q.lev_per_wg = walk < q.nlev ? walk : q.nlev;
           const unsigned gy = (q.nlev + q.lev_per_wg - 1) / q.lev_per_wg;
           const dim3 g((unsigned)band, gy, (unsigned)((ntx + band - 1) / band));
-#define EKM_LEV_LAUNCH(PM_, AL_, WALK_) hipLaunchKernelGGL((map_levels<Op, T, PM_, AL_, WALK_>), g, dim3(NT), 0, s, q)
+#define EKM_LEV_LAUNCH(PM_, WALK_) hipLaunchKernelGGL((map_levels<Op, T, PM_, WALK_>), g, dim3(NT), 0, s, q)
           if (pmode == PM_LEVEL) {
-            if (al) EKM_LEV_LAUNCH(PM_LEVEL, true, false); else EKM_LEV_LAUNCH(PM_LEVEL, false, false);
+            EKM_LEV_LAUNCH(PM_LEVEL, false);
           } else if (pmode == PM_FLAT) {
-            if (al) EKM_LEV_LAUNCH(PM_FLAT, true, false); else EKM_LEV_LAUNCH(PM_FLAT, false, false);
+            EKM_LEV_LAUNCH(PM_FLAT, false);
           } else if (kWalk && q.lev_per_wg > 1) {
-            if constexpr (kWalk) {
-              if (al) EKM_LEV_LAUNCH(PM_HYBRID, true, true); else EKM_LEV_LAUNCH(PM_HYBRID, false, true);
-            }
+            if constexpr (kWalk) EKM_LEV_LAUNCH(PM_HYBRID, true);
           } else {
-            if (al) EKM_LEV_LAUNCH(PM_HYBRID, true, false); else EKM_LEV_LAUNCH(PM_HYBRID, false, false);
+            EKM_LEV_LAUNCH(PM_HYBRID, false);
           }
 #undef EKM_LEV_LAUNCH
         };

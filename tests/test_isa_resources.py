@@ -35,9 +35,9 @@ def test_no_pipeline_kernel_uses_scratch_memory(kernels):
 
 
 def test_the_benchmarked_pipeline_kernels_keep_five_waves_per_simd(kernels):
-    # map_fields<OpPipelineFull, float, 1> and the aligned per-level instantiations (level vector, flat, hybrid)
+    # map_fields<OpPipelineFull, float, 1> and the per-level instantiations (level vector, flat, hybrid; no level walk)
     want = [k for k in kernels if "14OpPipelineFullEf" in k and ("map_fieldsINS_14OpPipelineFullEfLi1E" in k or
-                                                                  ("map_levels" in k and "ELb1ELb0E" in k))]
+                                                                  ("map_levels" in k and "ELb0EEEv" in k))]
     assert len(want) == 4, want
     for k in want:
         assert kernels[k][0] <= 96, (k, kernels[k])
@@ -65,7 +65,7 @@ def built_kernels(tmp_path_factory):
             get = lambda key: re.search(r"^    \." + key + r":\s*(\S+)", block, re.M).group(1)  # noqa: E731
             found[get("name")] = {"vgpr": int(get("vgpr_count")), "scratch": int(get("private_segment_fixed_size")),
                                   "lds": int(get("group_segment_fixed_size")), "threads": int(get("max_flat_workgroup_size"))}
-    assert len(found) > 1500, len(found)
+    assert len(found) > 1000, len(found)
     return found
 
 
@@ -85,7 +85,7 @@ def test_tree_walk_kernels_keep_their_occupancy(built_kernels):
     """512 threads around one copy of the tree: fp32 48 KiB and <= 80 registers (three workgroups = six waves per SIMD),
     fp64 80 KiB and <= 128 registers (two workgroups = four waves per SIMD); no two-tile or level-walk instantiation."""
     tree = {k: v for k, v in built_kernels.items() if TREE.search(k) and ("map_fields" in k or "map_levels" in k or "map_bcast" in k)}
-    assert len(tree) >= 2 * 15 * 8, len(tree)
+    assert len(tree) == 2 * 15 * 5, len(tree)   # map_fields, map_bcast, map_levels x (level vector, flat, hybrid)
     for k, v in tree.items():
         f64 = re.search(r"EEEd(Li|EE)", k) is not None
         assert v["threads"] == 512, (k, v)
@@ -93,12 +93,12 @@ def test_tree_walk_kernels_keep_their_occupancy(built_kernels):
         if "map_bcast" not in k:
             assert v["vgpr"] <= (128 if f64 else 80), (k, v)
         assert not re.search(r"map_fields.*Li2EEEv", k), k                      # UNROLL = 2
-        assert not re.search(r"map_levels.*ELb[01]ELb1EEEv", k), k              # WALK
+        assert not re.search(r"map_levels.*Li\dELb1EEEv", k), k                 # WALK
 
 
 def test_six_output_pipeline_kernels_of_the_built_library(built_kernels):
     want = [k for k in built_kernels if "14OpPipelineFullEf" in k and ("map_fieldsINS_14OpPipelineFullEfLi1E" in k or
-                                                                        ("map_levels" in k and "ELb1ELb0E" in k))]
+                                                                        ("map_levels" in k and "ELb0EEEv" in k))]
     assert len(want) == 4, want
     for k in want:
         assert built_kernels[k]["vgpr"] <= 96 and built_kernels[k]["scratch"] == 0 and built_kernels[k]["lds"] == 0, (k, built_kernels[k])
