@@ -84,7 +84,6 @@ struct MapArgs {
   unsigned long long inner[NIN]; // LEVEL_MAJOR: points per level
   unsigned long long step_q[NIN];  // (elements per tile) / inner   resp. unused
   unsigned long long step_r[NIN];  // (elements per tile) % inner   resp. % len
-  int vec_ok;                    // always 1 since round 4 (element-aligned pointers are enough for the 16-B accesses)
   int switches;                  // test / A-B switches: bit 0 fp64: redo every lane in plain double (tuning parameter f64_plain);
                                  // bit 1 fp32 IFS bisection: the exact residual at every step (bisect_exact)
   const T* aux0;                 // EKM_HYBRID_FULL (last operand): A half-level table
@@ -371,7 +370,7 @@ __global__ __launch_bounds__((OpThreads<Op, T>::value)) void map_bcast(const Map
 #pragma unroll
       for (int i = 0; i < NIN; ++i) {
         if (a.mode[i] == EKM_FIELD) {
-          if (full && a.vec_ok) {
+          if (full) {
             xin[i] = ld_stream<T>(a.in[i] + e0);
           } else {
 #pragma unroll
@@ -420,7 +419,7 @@ __global__ __launch_bounds__((OpThreads<Op, T>::value)) void map_bcast(const Map
       }
 #pragma unroll
       for (int o = 0; o < NOUT; ++o) {
-        if (full && a.vec_ok) {
+        if (full) {
           st_stream<T>(a.out[o] + e0, yout[o]);
         } else {
 #pragma unroll
@@ -810,7 +809,6 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
     if (reinterpret_cast<uintptr_t>(outs[o]) % sizeof(T)) aligned = false;
   }
   if (!aligned) return set_error(EKM_ERR_ARG, "a field pointer is not aligned to its element size (%d B)", (int)sizeof(T));
-  a.vec_ok = 1;
   // staged level vectors: at most 32 KiB of dynamic LDS (what the host layer hands over at most); the op's own
   // per-workgroup table is static LDS on top of that (the CU has 160 KiB)
   if ((size_t)lds_elems * sizeof(T) > kMaxLdsBytes)
