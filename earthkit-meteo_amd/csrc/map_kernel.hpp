@@ -969,7 +969,21 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
         a.step_r[i] = step % a.len[i];
       }
     }
-    hipLaunchKernelGGL((map_bcast<Op, T>), dim3(grid), dim3(NT), lds_elems * sizeof(T), s, a, tiles);
+    // every workgroup stages the level vectors in LDS before its first tile: with one 1024-element tile per workgroup a
+    // 3600-element vector cost 3.5 x the payload in staging reads (theta against a trailing-axis vector: 0.49 of the
+    // full-field rate).  Enough tiles per workgroup that the staging is <= 1/16 of its elements, while the grid still
+    // holds >= 4 workgroups per CU.
+    unsigned btiles = tiles;
+    if (lds_elems > 0) {
+      const unsigned long long want = (16ull * lds_elems + (unsigned long long)NT * V - 1) / ((unsigned long long)NT * V);
+      const int cus = device_cus(dev);
+      unsigned long long most = ntile / (4ull * (unsigned long long)(cus > 0 ? cus : 256));
+      if (most < 1) most = 1;
+      const unsigned long long t = want < most ? want : most;
+      if (t > btiles) btiles = (unsigned)(t < 4096 ? t : 4096);
+    }
+    const unsigned bgrid = (unsigned)((ntile + btiles - 1) / btiles);
+    hipLaunchKernelGGL((map_bcast<Op, T>), dim3(bgrid), dim3(NT), lds_elems * sizeof(T), s, a, btiles);
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return set_error(EKM_ERR_HIP, "kernel launch: %s", hipGetErrorString(err));
