@@ -553,10 +553,15 @@ class _PinnedPool:
             self.used[b] = self.tick
             if b <= self.limit:
                 while self.cached + b > self.limit:
-                    old = min((k for k, lst in self.free.items() if lst and k != b), key=lambda k: self.used.get(k, 0), default=None)
-                    if old is None:
+                    # (a snapshot: a finalizer fired by the garbage collector can re-enter give() right here)
+                    sizes = [k for k, lst in list(self.free.items()) if lst and k != b]
+                    if not sizes:
                         break
-                    evicted.append(self.free[old].pop())
+                    old = min(sizes, key=lambda k: self.used.get(k, 0))
+                    lst = self.free.get(old)
+                    if not lst:
+                        continue
+                    evicted.append(lst.pop())
                     self.cached -= old
                 if self.cached + b <= self.limit:
                     self.free.setdefault(b, []).append(ptr)
