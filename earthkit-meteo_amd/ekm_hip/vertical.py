@@ -384,3 +384,10 @@ class HybridPressure:
     @property
     def shape(self):
         return (self.nlev,) + tuple(np.shape(self.sp))
+
+
+# `earthkit.meteo.vertical.array.<name>` is how the reference reaches the array-level functions
+# (vertical/__init__.py:20, vertical/array/__init__.py:14-15): same module here.
+import sys as _sys  # noqa: E402
+
+array = _sys.modules[__name__]

@@ -185,3 +185,15 @@ def test_foreign_device_arrays_are_adopted_implicitly(monkeypatch):
     back = _engine._hand_back((h, np.float64(2.5)), ("fakelib", "host"))
     assert back[0][0] == "fakelib tensor" and back[0][1] is h and back[1] == ("fakelib scalar", np.float64(2.5))
     assert _engine._hand_back((h,), ("not_imported_lib", "host")) == (h,)
+
+
+def test_array_namespaces_as_in_the_reference():
+    """earthkit.meteo.{thermo,vertical,wind}.array.<name> is where the reference keeps its array-level functions
+    (thermo/array/__init__.py:14, vertical/array/__init__.py:14-15, wind/array/__init__.py): the same names resolve here."""
+    import ekm_hip
+
+    assert ekm_hip.thermo.array.potential_temperature is ekm_hip.thermo.potential_temperature
+    assert ekm_hip.vertical.array.pressure_on_hybrid_levels is ekm_hip.vertical.pressure_on_hybrid_levels
+    assert ekm_hip.vertical.array.hybrid_level_parameters is ekm_hip.vertical.hybrid_level_parameters
+    assert ekm_hip.vertical.array.height_on_hybrid_levels is ekm_hip.vertical.height_on_hybrid_levels
+    assert ekm_hip.wind.array.w_from_omega is ekm_hip.wind.w_from_omega
