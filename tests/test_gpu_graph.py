@@ -210,3 +210,54 @@ def test_example_recorded_forecast_steps():
     want = mod.diagnostics(fields[-1][0], fields[-1][1], p)
     for a, b in zip(p_seen, want):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_two_threads_record_and_replay_their_own_graphs():
+    """The recording state is per thread (and relaxed capture is per stream): two threads record different sequences at the
+    same time, replay them side by side, and a third runs eager calls meanwhile -- every result equals the eager one."""
+    import threading
+
+    t, q, p = fields(np.float32, 41)
+    want = {"rh": thermo.relative_humidity_from_specific_humidity(t, q, p), "td": thermo.dewpoint_from_specific_humidity(q, p),
+            "th": thermo.potential_temperature(t, p), "es": thermo.saturation_vapour_pressure(t)}
+    errors, start = [], threading.Barrier(3)
+
+    def recorder(names):
+        try:
+            d = {k: ekm_hip.to_device(v) for k, v in (("t", t), ("q", q), ("p", p))}
+            start.wait(timeout=60)
+            with ekm_hip.graph() as g:
+                outs = {}
+                if "rh" in names:
+                    outs["rh"] = thermo.relative_humidity_from_specific_humidity(d["t"], d["q"], d["p"])
+                    outs["td"] = thermo.dewpoint_from_specific_humidity(d["q"], d["p"])
+                else:
+                    outs["th"] = thermo.potential_temperature(d["t"], d["p"])
+                    outs["es"] = thermo.saturation_vapour_pressure(d["t"])
+            for _ in range(25):
+                g.launch()
+            for k, o in outs.items():
+                if not np.array_equal(o.to_host(), want[k], equal_nan=True):
+                    errors.append(f"{k} differs")
+            g.close()
+        except Exception as exc:  # surfaced in the test thread
+            errors.append(repr(exc))
+
+    def eager():
+        try:
+            d = [ekm_hip.to_device(v) for v in (t, q, p)]
+            start.wait(timeout=60)
+            for _ in range(50):
+                got = thermo.relative_humidity_from_specific_humidity(*d)
+            if not np.array_equal(got.to_host(), want["rh"], equal_nan=True):
+                errors.append("eager rh differs")
+        except Exception as exc:
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=recorder, args=(("rh",),)), threading.Thread(target=recorder, args=(("th",),)),
+               threading.Thread(target=eager)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errors, errors
