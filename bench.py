@@ -95,6 +95,8 @@ def parse():
                     help="roofline VALU side (executed issue units per point): 'measure' = a third rocprofv3 child pass of this "
                          "command (--pmc SQ_INSTS_VALU ..., N = 1 only; falls back to 'file' with the reason stated); 'file' = the "
                          "committed profiles/valu_latest.json; 'none' = HBM roof only")
+    ap.add_argument("--no-stream-ceiling", dest="stream_ceiling", action="store_false",
+                    help="skip roofline.stream_ceiling (the no-arithmetic streaming reference timed on the launch's own arrays)")
     ap.add_argument("--sustain", type=float, default=2.0,
                     help="after the timed region, keep launching the same step back to back for at least this many seconds and "
                          "report it as `sustained` (0 = skip); K timed steps stay what --steps asked for")
@@ -483,6 +485,37 @@ def main():
     # parity: rank 0 judges a sample of its own shard AND, at N > 1, a sample of the LAST rank's shard (whose first point is
     # not point 0 of the field), which travels through the gather together with the sample's place in the global field
     smp = None if args.dry_run else sample_shard(args, t, q, p, plev, outs, sh, nlev, np_dtype, hyb)
+    # The streaming reference of THIS launch on THESE buffers (the sample above is on the host by now: the outputs are
+    # overwritten): the same input fields read and the same output fields written by a kernel that computes nothing
+    # (ekm_stream_mix: the map kernels' launch shape, one add per stream).  The same kernel is 5-10 % faster or slower from
+    # process to process (where the 3.5-GB fields land in physical memory); this ceiling shares the placement.
+    ceiling_ms = None
+    if not args.dry_run and args.stream_ceiling:
+        with_p = {"pipeline_full": [t, q, p], "pipeline_svp_td_rh": [t, q, p], "wet_bulb_temperature_from_specific_humidity": [t, q, p],
+                  "relative_humidity_from_specific_humidity": [t, q, p], "ept_from_specific_humidity": [t, q, p],
+                  "potential_temperature": [t, p]}
+        if entry in with_p:  # the pressure is a stream only when it is a field
+            fields_in = with_p[entry] if args.pmode == "field" else with_p[entry][:-1]
+        else:
+            fields_in = {"saturation_vapour_pressure": [t], "pressure_on_hybrid_levels": [], "geopotential_on_hybrid_levels": [t, q]}[entry]
+        nbytes = (n_local * itemsize) // 16 * 16
+        ins_arr = (C.c_void_p * max(1, len(fields_in)))(*[x.ptr for x in fields_in])
+        outs_arr = (C.c_void_p * len(outs))(*[o.ptr for o in outs])
+        if len(outs) in (1, 2, 3, 6):
+            mix = lambda: _ffi.check(lib.ekm_stream_mix(dev, None, ins_arr, len(fields_in), outs_arr, len(outs), nbytes))  # noqa: E731
+            e0, e1 = C.c_void_p(), C.c_void_p()
+            _ffi.check(lib.ekm_event_create(dev, C.byref(e0)))
+            _ffi.check(lib.ekm_event_create(dev, C.byref(e1)))
+            for _ in range(3):
+                mix()
+            _ffi.check(lib.ekm_event_record(dev, e0, None))
+            for _ in range(10):
+                mix()
+            _ffi.check(lib.ekm_event_record(dev, e1, None))
+            sync()
+            _ffi.check(lib.ekm_event_elapsed_ms(dev, e0, e1, C.byref(ms)))
+            ceiling_ms = dist.reduce(ms.value / 10, "max")
+            ceiling_streams = (len(fields_in), len(outs))
     last_smp = dist.gather_object(smp if dist.rank == dist.world - 1 else None)
     parity_last, shard_window = None, None
     if not args.dry_run and dist.rank == 0:
@@ -553,6 +586,16 @@ def main():
                                 hbm_frac=round(achieved / HBM_PEAK_GBS, 4))
             else:
                 roof["valu_source"] = why_not
+            if ceiling_ms:
+                # bytes the reference moves: its streams x the field size (the kernel's algorithmic bytes may be a little less
+                # or more: a per-level pressure costs nothing, hybrid levels re-read sp from L2)
+                c_bytes = sum(ceiling_streams) * itemsize * n_local
+                roof["stream_ceiling"] = {
+                    "what": "ekm_stream_mix on the arrays of this launch: the same %d input and %d output fields moved with the "
+                            "map kernels' launch shape and no arithmetic, 10 launches after the timed region" % ceiling_streams,
+                    "kernel_ms": round(ceiling_ms, 4), "gbs": round(c_bytes / (ceiling_ms * 1e-3) / 1e9, 1),
+                    "frac": round(c_bytes / (ceiling_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "kernel_ms_over_ceiling_ms": round(kernel_ms / ceiling_ms, 4)}
             if sustained:
                 s_ach = bpp * n_local / (sustained["kernel_ms"] * 1e-3) / 1e9
                 sustained["frac"] = round(s_ach / HBM_PEAK_GBS, 4) if roof["bound"] == "hbm" else round(
@@ -719,7 +762,7 @@ def valu_from_profiles(args, why=""):
 
 def _child_cmd(args, steps, warm):
     return [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline",
-            "--traffic", "none", "--valu", "none", "--sustain", "0", "--workload", args.workload, "--pmode", args.pmode,
+            "--traffic", "none", "--valu", "none", "--sustain", "0", "--no-stream-ceiling", "--workload", args.workload, "--pmode", args.pmode,
             "--dtype", args.dtype, "--levels", str(args.levels)]
 
 

@@ -230,6 +230,42 @@ void register_table_prep(table_prep_fn fn) {
 }
 }  // namespace ekm
 
+namespace ekm {
+// ---- the streaming reference of a launch: R input streams read, W output streams written, nothing computed -------------
+// The map kernels' launch shape (256 lanes, 4-KiB tiles handed out in order, one 16-B non-temporal access per lane per
+// stream) with one add per stream in place of the thermodynamics: what the memory system gives THIS set of buffers --
+// bench.py times it on the arrays of the launch it has just measured, so that the kernel is compared with a ceiling that
+// shares its placement (the same kernel moves by 5-10 % between processes: profiles/r04_stream_mix.txt).
+struct MixPtrs {
+  const void* in[4];
+  void* out[8];
+};
+typedef float mix_vec __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int R, int W>
+__global__ __launch_bounds__(256) void stream_mix(MixPtrs p, unsigned long long nvec) {
+  const unsigned long long v = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= nvec) return;
+  mix_vec acc = {1.0f, 2.0f, 3.0f, 4.0f};
+#pragma unroll
+  for (int i = 0; i < R; ++i) acc += __builtin_nontemporal_load(static_cast<const mix_vec*>(p.in[i]) + v);
+#pragma unroll
+  for (int o = 0; o < W; ++o) __builtin_nontemporal_store(acc + (float)o, static_cast<mix_vec*>(p.out[o]) + v);
+}
+
+template <int R>
+static int stream_mix_launch(int nout, const MixPtrs& p, unsigned long long nvec, hipStream_t s) {
+  const dim3 g((unsigned)((nvec + 255) / 256)), b(256);
+  switch (nout) {
+    case 1: hipLaunchKernelGGL((stream_mix<R, 1>), g, b, 0, s, p, nvec); return EKM_OK;
+    case 2: hipLaunchKernelGGL((stream_mix<R, 2>), g, b, 0, s, p, nvec); return EKM_OK;
+    case 3: hipLaunchKernelGGL((stream_mix<R, 3>), g, b, 0, s, p, nvec); return EKM_OK;
+    case 6: hipLaunchKernelGGL((stream_mix<R, 6>), g, b, 0, s, p, nvec); return EKM_OK;
+    default: return set_error(EKM_ERR_ARG, "stream_mix: %d output streams (1, 2, 3 or 6)", nout);
+  }
+}
+}  // namespace ekm
+
 using namespace ekm;
 
 extern "C" {
@@ -570,6 +606,35 @@ int ekm_synth_fill_given_p_f64(int dev, void* stream, double* t, double* q, cons
   if (!p) return set_error(EKM_ERR_ARG, "synth_fill_given_p: null p");
   return synth_fill_launch<double>(dev, stream, t, q, const_cast<double*>(p), first, n, 1, 1, seed, 1);
 }
+int ekm_stream_mix(int dev, void* stream, const void* const* ins, int nin, void* const* outs, int nout, size_t bytes) {
+  if (nin < 0 || nin > 3 || !outs || (nin > 0 && !ins)) return set_error(EKM_ERR_ARG, "stream_mix: 0..3 input streams");
+  if (bytes % 16 != 0 || bytes / 16 / 256 > 0x7fffffffull) return set_error(EKM_ERR_ARG, "stream_mix: bytes must be a multiple of 16 (and < 2^43)");
+  MixPtrs p{};
+  for (int i = 0; i < nin; ++i) {
+    if (!ins[i] || reinterpret_cast<uintptr_t>(ins[i]) % 4) return set_error(EKM_ERR_ARG, "stream_mix: null or unaligned input %d", i);
+    p.in[i] = ins[i];
+  }
+  for (int o = 0; o < nout && o < 8; ++o) {
+    if (!outs[o] || reinterpret_cast<uintptr_t>(outs[o]) % 4) return set_error(EKM_ERR_ARG, "stream_mix: null or unaligned output %d", o);
+    p.out[o] = outs[o];
+  }
+  if (bytes == 0) return EKM_OK;
+  int rc = use_device(dev);
+  if (rc != EKM_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned long long nvec = bytes / 16;
+  switch (nin) {
+    case 0: rc = stream_mix_launch<0>(nout, p, nvec, s); break;
+    case 1: rc = stream_mix_launch<1>(nout, p, nvec, s); break;
+    case 2: rc = stream_mix_launch<2>(nout, p, nvec, s); break;
+    default: rc = stream_mix_launch<3>(nout, p, nvec, s); break;
+  }
+  if (rc != EKM_OK) return rc;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(EKM_ERR_HIP, "stream_mix launch: %s", hipGetErrorString(e));
+  return EKM_OK;
+}
+
 int ekm_synth_levels_f32(int dev, void* stream, float* p_levels, uint32_t nlev) {
   return synth_levels_launch<float>(dev, stream, p_levels, nlev);
 }

@@ -72,6 +72,7 @@ def _signatures():
         "ekm_synth_fill_given_p_f32": ([i, vp, vp, vp, vp, u64, sz, u64], i),
         "ekm_synth_fill_given_p_f64": ([i, vp, vp, vp, vp, u64, sz, u64], i),
         "ekm_synth_levels_f32": ([i, vp, vp, u32], i), "ekm_synth_levels_f64": ([i, vp, vp, u32], i),
+        "ekm_stream_mix": ([i, vp, pvp, i, pvp, i, sz], i),
     }
     for tag, real in (("f32", C.c_float), ("f64", C.c_double)):
         sig[f"ekm_pressure_on_hybrid_levels_{tag}"] = (

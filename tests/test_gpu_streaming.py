@@ -354,6 +354,10 @@ def test_bench_measures_its_hbm_traffic_in_the_run(ek):
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     roof = d["roofline"]
     assert d["parity"]["ok"] and roof["bound"] == "hbm" and d["oversubscribed"] is False
+    # the streaming reference timed on the launch's own arrays: nine streams, no arithmetic; the pipeline is within a few
+    # per cent of it (generous bounds: 16 levels are a short launch)
+    c = roof["stream_ceiling"]
+    assert c["kernel_ms"] > 0 and 0.3 < c["frac"] < 1.0 and 0.8 < c["kernel_ms_over_ceiling_ms"] < 1.5, c
     if shutil.which("rocprofv3") is None:
         pytest.skip("rocprofv3 not on PATH: " + roof["traffic_source"][:80])
     assert roof["traffic_source"].startswith("measured in this run"), roof["traffic_source"]

@@ -244,6 +244,11 @@ EKM_API int ekm_synth_fill_given_p_f32(int dev, void* stream, float* t, float* q
                                        size_t n, uint64_t seed);
 EKM_API int ekm_synth_fill_given_p_f64(int dev, void* stream, double* t, double* q, const double* p, uint64_t first,
                                        size_t n, uint64_t seed);
+/* The streaming reference of a launch (a benchmark helper like the two above): reads `nin` (0..3) and writes `nout` (1, 2, 3
+ * or 6) streams of `bytes` bytes each with the map kernels' launch shape and one add per stream -- what the memory system
+ * gives this set of buffers; bench.py times it on the arrays of the launch it has just measured (roofline.stream_ceiling).
+ * The outputs are OVERWRITTEN. */
+EKM_API int ekm_stream_mix(int dev, void* stream, const void* const* ins, int nin, void* const* outs, int nout, size_t bytes);
 EKM_API int ekm_synth_levels_f32(int dev, void* stream, float* p_levels, uint32_t nlev);
 EKM_API int ekm_synth_levels_f64(int dev, void* stream, double* p_levels, uint32_t nlev);
 
