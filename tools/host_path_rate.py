@@ -16,7 +16,8 @@ import ekm_hip  # noqa: E402
 from ekm_hip import _engine, thermo  # noqa: E402
 from oracle import synthetic  # noqa: E402
 
-for nlev in (8, 32):
+LEVELS = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [8, 32]   # e.g. "1,2,4" for mid-size calls
+for nlev in LEVELS:
     t, q, p, _ = synthetic.make_fields(nlev, 1800 * 3600, dtype=np.float32, seed=3)
     n = t.size
     for mode in ("pageable", "pooled", "pooled+in"):
