@@ -17,6 +17,8 @@ from ekm_hip import _engine, thermo  # noqa: E402
 from oracle import synthetic  # noqa: E402
 
 LEVELS = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [8, 32]   # e.g. "1,2,4" for mid-size calls
+if len(sys.argv) > 2:  # input bytes from which a call is streamed in slices (MB; the library's default: _engine._STREAM_BYTES)
+    _engine._STREAM_BYTES = int(sys.argv[2]) << 20
 for nlev in LEVELS:
     t, q, p, _ = synthetic.make_fields(nlev, 1800 * 3600, dtype=np.float32, seed=3)
     n = t.size
