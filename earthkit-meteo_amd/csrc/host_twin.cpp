@@ -13,11 +13,16 @@
 
 // Ops that keep a per-workgroup LDS table on the device (ops.hpp::OpTable, the bisection lattice) take the SAME path
 // here -- table filled once, OpTable<Op>::apply per point -- so the table arithmetic the kernels run is what the golden
-// vectors check.  EKM_TWIN_TABLE_FREE=1 selects Op::apply, the table-free statement of the same search.
+// vectors check.  EKM_TWIN_TABLE_FREE=1 selects Op::apply, the table-free statement of the same search;
+// EKM_TWIN_BISECT_EXACT=1 makes every step of the tree walk take the reference's own residual (the kernels' tuning
+// parameter bisect_exact), against which tests/test_hosttwin_fuzz.py compares the default walk bit for bit.
 template <class Op, class T>
 static int host_map(const T* const* ins, T* const* outs, size_t n, double rp) {
   std::vector<T> tab;
+  bool all_exact = false;
   if constexpr (ekm::OpTable<Op>::elems > 0) {
+    const char* ex = std::getenv("EKM_TWIN_BISECT_EXACT");
+    all_exact = ex && ex[0] == '1';
     const char* env = std::getenv("EKM_TWIN_TABLE_FREE");
     if (!(env && env[0] == '1')) {
       tab.resize(ekm::OpTable<Op>::template count<T>());
@@ -29,6 +34,7 @@ static int host_map(const T* const* ins, T* const* outs, size_t n, double rp) {
   // EKM_TWIN_PLAIN_F64=1 skips the first pass.
   const char* plain = std::getenv("EKM_TWIN_PLAIN_F64");  // read per call: tests compare the two in one process
   const bool two_pass = !(plain && plain[0] == '1');
+  (void)all_exact;
   for (size_t i = 0; i < n; ++i) {
     T x[Op::NIN], y[Op::NOUT];
     for (int k = 0; k < Op::NIN; ++k) x[k] = ins[k][i];
@@ -38,7 +44,7 @@ static int host_map(const T* const* ins, T* const* outs, size_t n, double rp) {
         for (int k = 0; k < Op::NIN; ++k) xf[k] = ekm::fdouble(x[k]);
         if constexpr (ekm::OpTable<Op>::elems > 0) {
           if (!tab.empty())
-            ekm::OpTable<Op>::template apply<ekm::fdouble>(xf, yf, ekm::fdouble(rp), reinterpret_cast<const ekm::fdouble*>(tab.data()));
+            ekm::OpTable<Op>::template apply<ekm::fdouble>(xf, yf, ekm::fdouble(rp), reinterpret_cast<const ekm::fdouble*>(tab.data()), all_exact);
           else
             Op::template apply<ekm::fdouble>(xf, yf, ekm::fdouble(rp));
         } else {
@@ -54,7 +60,7 @@ static int host_map(const T* const* ins, T* const* outs, size_t n, double rp) {
     }
     if constexpr (ekm::OpTable<Op>::elems > 0) {
       if (!tab.empty())
-        ekm::OpTable<Op>::template apply<T>(x, y, T(rp), tab.data());
+        ekm::OpTable<Op>::template apply<T>(x, y, T(rp), tab.data(), all_exact);
       else
         Op::template apply<T>(x, y, T(rp));
     } else {

@@ -236,11 +236,11 @@ struct BisectOp : BisectTable<METHOD> {
     for (int j = 0; j < V; ++j) y[j][0] = out[j];
   }
   template <class T>
-  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T rp, const T* __restrict__ tab) {
+  EKM_HD static void apply(const T* __restrict__ x, T* __restrict__ y, T rp, const T* __restrict__ tab, bool all_exact = false) {
     T xx[1][NIN_], yy[1][1];
 #pragma unroll
     for (int i = 0; i < NIN_; ++i) xx[0][i] = x[i];
-    apply_v<T, 1>(xx, yy, rp, tab);
+    apply_v<T, 1>(xx, yy, rp, tab, all_exact);
     y[0] = yy[0][0];
   }
 };

@@ -10,7 +10,8 @@
 // (v_exp_f32 / v_log_f32 / v_rcp_f32 via __builtin_amdgcn_*): no libm calls,
 // no IEEE division expansion.  NaN / inf semantics of the reference are kept
 // (no -ffast-math): rcp(0)=inf, log2(0)=-inf, log2(<0)=NaN, 0*inf=NaN.
-// fp64 has no hardware transcendentals; it uses the device libm (ocml).
+// fp64 has no hardware transcendentals: rcp / exp2 / log2 are built here from v_rcp_f64, v_ldexp_f64, v_frexp_* and
+// short polynomials (below); the device libm (ocml) is used only by the -DEKM_F64_LIBM diagnostic build.
 #pragma once
 
 #include <cmath>
@@ -150,10 +151,10 @@ EKM_HD float m_pow(float x, float y) { return std::pow(x, y); }
 // fp64 on gfx950: there is no fp64 transcendental unit and the device libm pays for correctly rounded
 // results (pow alone is ~200 instructions).  Measured issue cost (tools/microbench/valu_rates_f64.hip):
 // v_fma_f64 5.2 clk per wave, v_rcp_f64 17 clk.  The parity bar for fp64 is 1e-6 relative, so by default
-// the three primitives are built to ~1e-11 (five orders inside the bar, one order inside the 1e-8 the
-// GPU tests assert against the reference's fp64 goldens):
+// the three primitives are built to ~1e-10 (four orders inside the bar; the GPU tests assert <= 1e-9 against the
+// reference's fp64 goldens):
 //   rcp  = v_rcp_f64 seed + ONE Newton step (<= 1e-14);
-//   exp2 = round-to-nearest split + degree-8 near-minimax polynomial of e^(f ln2) + v_ldexp_f64 (1.1e-12);
+//   exp2 = round-to-nearest split + degree-7 near-minimax polynomial of 2^f, ln 2 folded in + v_ldexp_f64 (4.0e-11);
 //   log2 = v_frexp + 2*atanh(s), s = (m-1)/(m+1), as s*q(s^2) with a degree-4 near-minimax q (4.2e-12);
 //   pow  = exp2(y*log2(x)).
 // -DEKM_F64_EXACT selects the <= 3e-16 versions (two Newton steps, degree-12 Taylor, atanh series to s^21)
@@ -464,6 +465,21 @@ EKM_HD void es_slope_ice(T t, T& es, T& des) {
   const T r = m_rcp(t - T(k::C4I));
   es = m_exp2(m_fma((t - T(k::T0)) * r, T(k::C3I * k::LOG2E), T(k::LOG2_C1)));
   des = es * T(k::si) * (r * r);
+}
+
+// Where the reference's es is exactly ZERO: its exp underflows (argument below ln 2^-150 resp. ln 2^-1075) for
+// t <= 48.175793 K in fp32 and t < 7.35720061305125 K in fp64 (largest / smallest such values found on the NumPy
+// restatement; one transition).  Only the Davies-Jones regime-1 guess cares: it divides des by es (thermo.py:1119), 0/0
+// there.  Above that temperature the reference's es is a denormal down to which v_exp_f32 does not go (it returns 0
+// below 2^-126, t < 52.5 K): such an es is nothing beside any pressure, and the formulas that divide by it take the
+// limit instead of the quotient.
+template <class T>
+EKM_HD T es_zero_below() {
+  return sizeof(T) == 4 ? T(48.175797f) : T(7.35720061305125);
+}
+template <class T>
+EKM_HD T es_negligible() {
+  return sizeof(T) == 4 ? T(2e-38f) : T(1e-300);
 }
 
 // Mixed phase (es_comp.py:141-166).  The reference gathers three masks; per point that
@@ -837,17 +853,41 @@ EKM_HD unsigned bisect_heap_child(unsigned node, float r) {
 // with u = L_m - le, le = log2(theta_e/273.16) (`te` is theta_e itself for these methods; `kl` is read for bolton35 only).
 // D of one node (fp32): positive <=> the residual is positive, unless |D| <= the band (then `amb`).  w = the positive
 // denominator the exact step divides by (ifs: p + (eps-1)*es; Bolton: p - es); thr0 = the part of the band that goes with p.
+constexpr double kB35WsExact = 2.0;
+
+// exp2 whose result may be a denormal (v_exp_f32 flushes those to zero; the reference's exp / pow round them): only the
+// exact step of the bolton35 search, whose two terms are compared where both are that small, needs it
+EKM_HD float m_exp2_denorm(float x) { return x < -100.0f ? m_exp2(x + 64.0f) * 0x1p-64f : m_exp2(x); }
+EKM_HD double m_exp2_denorm(double x) { return m_exp2(x); }
+EKM_FD fd64<F> m_exp2_denorm(fd64<F> x) { return m_exp2(x); }
+
+// The reference's bolton35 residual as it stands, theta_e*exp(G_sat(scale=-1)) - th_sat (thermo.py:1075, 1215-1224), in
+// base 2: theta_e*2^(a_m*ws) - t_m*2^(kl*(0.28*ws - 1)), a_m = -2675*log2(e)/t_m, kl = kappa*log2(p/p0).  NOT divided by
+// th_sat/t_m: where ws is large both terms underflow and the reference's 0 - 0 = 0 keeps the search on the node.
+template <class T>
+EKM_HD T bisect_b35_residual(T te, T tm, T a, T ws, T kl) {
+  return m_fms(te, m_exp2_denorm(a * ws), tm * m_exp2_denorm(kl * m_fms(T(0.28), ws, T(1))));
+}
+
 template <int METHOD>
 EKM_HD float bisect_fast_test(float es, float a, float u, float p, float kl, float& w, float thr0, bool& amb) {
   float D, scale;  // scale: |a_m| resp. its counterpart -- the part of the band that goes with the size of the exponent
+  bool big_ws = false;
   if (METHOD == EPT_IFS) {
     w = m_fma(float(k::eps - 1), es, p);
     D = m_fnma(u, w, a);
     scale = a;
   } else if (METHOD == EPT_BOLTON35) {
     w = p - es;
-    scale = (float(k::eps) * es) * m_fnma(0.28f, kl, a);
+    const float ees = float(k::eps) * es;
+    scale = ees * m_fnma(0.28f, kl, a);
     D = m_fma(kl - u, w, scale);
+    // ws = eps*es/(p - es) >= kB35WsExact: the reference's two terms, theta_e*exp(-2675*ws/t) and th_sat =
+    // t*(p0/p)^(kappa*(1 - 0.28*ws)), can BOTH leave the normal range there (ws of several hundred where p - es is a
+    // fraction of a pascal: 0 - 0, sign 0, the reference stays on this node for good), and D -- the residual divided
+    // by th_sat/t -- no longer says what the reference's own subtraction gives.  Below the limit both terms are
+    // normal numbers (|exponents| <= 29*2 resp. 47*1.56) and the division changes nothing.  Decided by the exact step.
+    big_ws = !(w > float(kB35WsExact) * ees);
   } else {
     w = p - es;
     const float ees = float(k::eps) * es;
@@ -857,6 +897,7 @@ EKM_HD float bisect_fast_test(float es, float a, float u, float p, float kl, flo
     thr0 = float(2.0 * kHeapTau0) * v2;  // the band in units of v^2 here (log2 of a small v adds its own rounding)
   }
   amb = !(__builtin_fabsf(D) > m_fma(__builtin_fabsf(scale), float(METHOD == EPT_IFS ? kHeapTau1 : 2.0 * kHeapTau1), thr0));  // NaN: ambiguous
+  if (METHOD == EPT_BOLTON35) amb = amb || big_ws;
   return D;
 }
 
@@ -867,12 +908,16 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
   // order like the values and the running maximum is ONE v_max_u32 (v_max_f32 wants a canonicalising copy of a freshly
   // loaded operand in front of it)
   unsigned node[V], esmax[V], esfix[V];
-  float thr0[V], tfix[V];  // tfix: the final answer of a lane whose residual came out exactly zero or NaN; 0 = none yet
+  float thr0[V], tfix[V], lq[V];  // tfix: the final answer of a lane whose residual came out exactly zero or NaN; 0 = none yet
 #pragma unroll
   for (int j = 0; j < V; ++j) {
     node[j] = 1u;
     esmax[j] = esfix[j] = 0u;
     thr0[j] = float(kHeapTau0) * p[j];
+    // an infinite theta_e (fp32 overflow of its exponential for q of 0.8) times an exp(G_sat) that underflowed is NaN in the
+    // reference where the logarithmic test reads +inf: with a NaN logarithm every test of such a point is NaN, i.e.
+    // ambiguous, and every step takes the reference's own residual
+    lq[j] = (METHOD != EPT_IFS && !(lte[j] < std::numeric_limits<float>::infinity())) ? nan_v<float>() : lte[j];
     tfix[j] = 0.0f;
   }
   const char* __restrict__ pairs = reinterpret_cast<const char*>(tab);
@@ -893,7 +938,7 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
       es[j] = tab[2 * node[j]];
       a[j] = tab[2 * node[j] + 1];
 #endif
-      const float u = *reinterpret_cast<const float*>(logs + (node[j] << 2)) - lte[j];
+      const float u = *reinterpret_cast<const float*>(logs + (node[j] << 2)) - lq[j];
       D[j] = bisect_fast_test<METHOD>(es[j], a[j], u, p[j], kl[j], w[j], thr0[j], amb[j]);
       const unsigned eb = __builtin_bit_cast(unsigned, es[j]);
       esmax[j] = esmax[j] > eb ? esmax[j] : eb;
@@ -905,17 +950,19 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
       for (int j = 0; j < V; ++j) {
         if (amb[j]) {
           const float tm = bisect_lattice_t<float>(bisect_heap_lattice((int)node[j], d));
-          float g;  // the stepwise search's step (above), operation for operation
-          if (METHOD == EPT_IFS) {
-            g = a[j] * m_rcp(w[j]);
+          float r;  // the stepwise search's step (above), operation for operation
+          if (METHOD == EPT_BOLTON35) {
+            r = bisect_b35_residual(te[j], tm, a[j], float(k::eps) * es[j] * m_rcp(w[j]), kl[j]);
           } else {
-            const float ws = float(k::eps) * es[j] * m_rcp(w[j]);
-            if (METHOD == EPT_BOLTON35)
-              g = m_fma(ws, m_fnma(0.28f, kl[j], a[j]), kl[j]);
-            else
+            float g;
+            if (METHOD == EPT_IFS) {
+              g = a[j] * m_rcp(w[j]);
+            } else {
+              const float ws = float(k::eps) * es[j] * m_rcp(w[j]);
               g = m_fma(a[j] * ws, m_fma(0.448f, ws, 1.0f), float(k::kappa) * m_log2(w[j] * float(1.0 / k::p0)));
+            }
+            r = m_fms(te[j], METHOD == EPT_IFS ? m_exp2(g) : m_exp2_denorm(g), tm);
           }
-          const float r = m_fms(te[j], m_exp2(g), tm);
           D[j] = r;
           if (!(r < 0.0f || r > 0.0f) && tfix[j] == 0.0f) {  // zero: the reference stays on this point; NaN: it turns NaN
             tfix[j] = r == 0.0f ? tm : r;  // (lattice temperatures are >= 133 K: never the "none" value)
@@ -966,6 +1013,7 @@ EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (
     pf[j] = (float)p[j];
     klf[j] = (float)kl[j];
     thr0[j] = float(1.5 * kHeapTau0) * pf[j];
+    if (METHOD != EPT_IFS && !(ltef[j] < std::numeric_limits<float>::infinity())) ltef[j] = nan_v<float>();  // as in the fp32 walk
     tfix[j] = T(0.0);
   }
   const char* __restrict__ pairs = reinterpret_cast<const char*>(heap);
@@ -1000,17 +1048,19 @@ EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (
           const T v = METHOD == EPT_IFS ? m_fma(T(k::eps - 1), es, p[j]) : p[j] - es;
           const T r1 = m_rcp(v * tm);
           const T rv = r1 * tm, a = bisect_second<METHOD>(es, r1 * v);
-          T g;
-          if (METHOD == EPT_IFS) {
-            g = a * rv;
+          T r;
+          if (METHOD == EPT_BOLTON35) {
+            r = bisect_b35_residual(te[j], tm, a, T(k::eps) * es * rv, kl[j]);
           } else {
-            const T ws = T(k::eps) * es * rv;
-            if (METHOD == EPT_BOLTON35)
-              g = m_fma(ws, m_fnma(T(0.28), kl[j], a), kl[j]);
-            else
+            T g;
+            if (METHOD == EPT_IFS) {
+              g = a * rv;
+            } else {
+              const T ws = T(k::eps) * es * rv;
               g = m_fma(a * ws, m_fma(T(0.448), ws, T(1)), T(k::kappa) * m_log2(v * T(1.0 / k::p0)));
+            }
+            r = m_fms(te[j], METHOD == EPT_IFS ? m_exp2(g) : m_exp2_denorm(g), tm);
           }
-          const T r = m_fms(te[j], m_exp2(g), tm);
           D[j] = r > T(0) ? 1.0f : -1.0f;
           if (!(r < T(0) || r > T(0)) && kfix[j] < 0) {
             kfix[j] = d;
@@ -1227,9 +1277,10 @@ EKM_HD T t_on_ma_newton_ifs_core(T lte, T p, T dinv, const TeFn& te_fn, const Pp
     T es, des;
     es_slope_mixed(te, es, des);
     // te - t0 - A*ws/(1 + A*ws*des/es) with ws = eps*es/v, v = p - es (thermo.py:1116-1119): the two divisions are one,
-    // A*eps*es/(v + A*eps*des).  v is NaN where p - es < eps, and es <= 0 (underflow) is the reference's 0*0/0.
+    // A*eps*es/(v + A*eps*des).  v is NaN where p - es < eps, and where the reference's es underflows to zero its
+    // des/es is 0/0 (es_zero_below; an es of ours that is zero above that temperature leaves te - t0, as it should).
     T v = p - es;
-    if (v < T(k::eps_default) || !(es > T(0))) v = nan_v<T>();
+    if (v < T(k::eps_default) || te < es_zero_below<T>()) v = nan_v<T>();
     const T g1 = m_fnma(T(2675 * k::eps) * es, m_rcp(m_fma(T(2675 * k::eps), des, v)), te - T(273.16));
     if (R.r1) tw = g1;
   }
@@ -1327,7 +1378,9 @@ EKM_HD T t_on_ma_newton(T e, T p, Tie& tie) {
     es_slope_mixed(te, es, des);
     const T ws = w_from_e(es, p, T(k::eps_default));
     const T aw = A * ws;
-    const T g1 = te - t0 - m_div(aw, T(1) + m_div(aw * des, es));
+    T dr = m_div(aw * des, es);  // A*ws*des/es (thermo.py:1119): 0/0 where the reference's es is zero, else nothing beside 1
+    if (!(es > es_negligible<T>()) && es == es) dr = te < es_zero_below<T>() ? nan_v<T>() : T(0);
+    const T g1 = te - t0 - m_div(aw, T(1) + dr);
     const T k1 = poly2(pp, -53.737, 137.81, -38.5);
     const T k2 = poly2(pp, -0.384, 56.831, -4.392);
     const TeFromEpt<T> exact{e, p};

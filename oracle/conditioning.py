@@ -73,24 +73,21 @@ def newton_regime_boundary(func, inputs, kwargs, thresh):
         return dist <= thresh
 
 
-def newton_amplification(t, q, p, h=1e-6, return_candidates=False):
-    """How strongly the reference's own one-step Newton wet-bulb (ifs) amplifies a relative perturbation of its
-    inputs, on the fp64 oracle: kappa = max over (t, q, p) of |tw(x(1+h)) - tw(x(1-h))| / (2 h |tw(x)|); inf where a
-    perturbed evaluation changes NaN-ness (the point sits on the edge of the p - es < eps / tw <= 0 NaN regions or on
-    a regime threshold).  At hPa-level pressures (p < ~60 Pa: es(tw) ~ p, qs ~ 1) the single Newton step is far
-    from converged and kappa reaches 1e3-1e6: an fp32 rounding of an intermediate (6e-8) then shows up at 1e-4 and
-    beyond in ANY fp32 evaluation, the reference's own included.  Identified from the oracle alone.
-    `return_candidates`: also the seven fp64 values themselves, [7, n]: the unperturbed one and the six perturbed."""
+def amplification(f, xs, h=1e-6, return_candidates=False):
+    """How strongly `f` (a function of the oracle, evaluated in fp64) amplifies a relative perturbation of its inputs
+    `xs`: kappa = max over the inputs of |f(x(1+h)) - f(x(1-h))| / (2 h |f(x)|); inf where a perturbed evaluation
+    changes NaN-ness (the point sits on the edge of a NaN region or on a regime threshold).  Identified from the oracle
+    alone.  `return_candidates`: also the 1 + 2*len(xs) fp64 values themselves: the unperturbed one and the perturbed."""
     with np.errstate(all="ignore"):
-        x = [np.asarray(a, dtype=np.float64) for a in (t, q, p)]
-        base = orc.wet_bulb_temperature_from_specific_humidity(*x, "ifs", "newton")
+        x = [np.asarray(a, dtype=np.float64) for a in xs]
+        base = f(*x)
         kappa = np.zeros(base.shape)
         cands = [base]
-        for i in range(3):
+        for i in range(len(x)):
             lo, hi = list(x), list(x)
             lo[i], hi[i] = x[i] * (1.0 - h), x[i] * (1.0 + h)
-            a = orc.wet_bulb_temperature_from_specific_humidity(*lo, "ifs", "newton")
-            b = orc.wet_bulb_temperature_from_specific_humidity(*hi, "ifs", "newton")
+            a = f(*lo)
+            b = f(*hi)
             k = np.abs(b - a) / (2.0 * h * np.abs(base))
             k = np.where(np.isnan(a) | np.isnan(b) | np.isnan(base), np.inf, k)
             kappa = np.maximum(kappa, k)
@@ -98,12 +95,25 @@ def newton_amplification(t, q, p, h=1e-6, return_candidates=False):
     return (kappa, np.stack(cands)) if return_candidates else kappa
 
 
-def newton_misses_explained(t, q, p, got, want, tol, h=1e-6):
-    """Which deviations of a one-step Newton wet-bulb `got` from the reference's `want` (same dtype run) the reference's
-    own conditioning explains -- from the fp64 oracle alone, never from `got`.  Returns two masks over the points:
-      * finite kappa: the deviation is within 8 x kappa x 2^-24 (kappa: newton_amplification);
+def _wb_ifs_newton(t, q, p):
+    return orc.wet_bulb_temperature_from_specific_humidity(t, q, p, "ifs", "newton")
+
+
+def newton_amplification(t, q, p, h=1e-6, return_candidates=False):
+    """`amplification` of the reference's own one-step Newton wet-bulb (ifs) over (t, q, p).  At hPa-level pressures
+    (p < ~60 Pa: es(tw) ~ p, qs ~ 1) the single Newton step is far from converged and kappa reaches 1e3-1e6: an fp32
+    rounding of an intermediate (6e-8) then shows up at 1e-4 and beyond in ANY fp32 evaluation, the reference's own
+    included."""
+    return amplification(_wb_ifs_newton, (t, q, p), h, return_candidates)
+
+
+def misses_explained(f, xs, got, want, tol, h=1e-6, unit=2.0 ** -24, factor=8.0):
+    """Which deviations of `got` from the reference's `want` (same dtype run) the reference's own conditioning explains
+    -- from the fp64 oracle `f` alone, never from `got`.  Returns two masks over the points:
+      * finite kappa: the deviation is within factor x kappa x unit (kappa: `amplification`; unit: the rounding unit of
+        the arithmetic under test, 2^-24 for fp32; factor: how many such roundings may add up, 8 on the benchmark field);
       * on a NaN / regime edge (kappa = inf: a 1e-6 perturbation of an input changes the NaN-ness of the fp64 result): the
-        value under test must BE one of the outcomes that edge offers -- NaN where the fp64 oracle or one of its six
+        value under test must BE one of the outcomes that edge offers -- NaN where the fp64 oracle or one of its
         perturbed evaluations is NaN, or a finite value inside the span [lo, hi] of the finite ones (the function is
         continuous on its finite side: every value in the span is the outcome of some perturbation within +-h), the
         span extended by its own width on both sides where the other side of the edge is NaN, and by `tol`.
@@ -114,9 +124,9 @@ def newton_misses_explained(t, q, p, got, want, tol, h=1e-6):
         nanmm = np.isnan(got) != np.isnan(want)
         r = np.abs(got - want) / np.abs(want)
         r = np.where(np.isfinite(r), r, 0.0)
-        kap, cands = newton_amplification(t, q, p, h, return_candidates=True)
+        kap, cands = amplification(f, xs, h, return_candidates=True)
         edge = np.isinf(kap)
-        finite = ~edge & ~nanmm & (r <= 8.0 * np.where(edge, 0.0, kap) * 2.0 ** -24)
+        finite = ~edge & ~nanmm & (r <= factor * np.where(edge, 0.0, kap) * unit)
         cn = np.isnan(cands)
         lo = np.min(np.where(cn, np.inf, cands), axis=0)
         hi = np.max(np.where(cn, -np.inf, cands), axis=0)
@@ -129,3 +139,8 @@ def newton_misses_explained(t, q, p, got, want, tol, h=1e-6):
         ok_range = some & (got >= lo_e - tol * np.abs(lo_e)) & (got <= hi_e + tol * np.abs(hi_e))
         on_edge = edge & np.where(np.isnan(got), cn.any(axis=0), ok_range)
     return finite, on_edge
+
+
+def newton_misses_explained(t, q, p, got, want, tol, h=1e-6):
+    """`misses_explained` for the one-step Newton wet-bulb (ifs) from (t, q, p)."""
+    return misses_explained(_wb_ifs_newton, (t, q, p), got, want, tol, h)

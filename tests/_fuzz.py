@@ -1,0 +1,141 @@
+"""Wide-domain fuzz of the moist-adiabat inversions -- shared by tests/test_hosttwin_fuzz.py (the kernels' templates
+compiled for the host, no GPU) and tests/test_gpu_fuzz.py (the gfx950 kernels through the C ABI).
+
+The benchmark generator keeps p >= 950 Pa and a physical theta_e; the reference's functions are
+total over broadcastable float input (thermo.py:1055-1079 runs for any ept, p).  This sweep covers what the benchmark
+field cannot reach: t in [150, 400] K uniform; p in [1, 1.26e5] Pa, q in [1e-7, 0.9], theta_e in [150, 3000] K
+log-uniform -- every theta_e method x {bisect, newton} x {fp32, fp64}, from (theta_e, p) and from (t, q, p).
+
+What is asserted, against the oracle run in the SAME dtype (the oracle is pinned to the reference, tests/golden):
+  * bisection: the anchored rule of tests/_compare.py::_assert_bisect -- identical NaN pattern and <= 2 quanta on every
+    point the reference decides stably; a reference-unstable point (its own residual below rounding noise at a visited
+    node, or its fp32 and fp64 runs disagree) needs one of the reference's own anchors;
+  * Newton (one Davies-Jones step, thermo.py:1081-1159): identical NaN pattern and <= 1e-4 (fp32) / <= 1e-7 (fp64, bar
+    1e-6), except where the reference's own last line, tw = guess - (f - c_te)/(f*dlnf), is ill-conditioned.  That is
+    decided from the oracle alone, never from the output under test; the bar of a point is the largest of
+      - 4*delta, delta = the reference's own fp32-vs-fp64 distance;
+      - 16 x unit x the first-order rounding bound of that line with every operand carrying roundings of its own size:
+        [|guess| + (|f| + |c_te|)/|f*dlnf| + |step|*((lambda/guess)/|dlnf| + guess*|d ln f/dT| + |ln f| + |ln c_te|)]/tw,
+        operands from the fp64 oracle (thermo_oracle._t_on_ma_newton(return_parts=True)): 2-5 on the benchmark
+        distribution (nothing relaxed), 1e3-1e6 where theta_e of 1000-3000 K or q of 0.1-0.9 makes the single step move
+        the guess by 50-250 K and land at 0.05 K or 1e15 K, or where bolton35's dlnf cancels to 1e-5 against terms of 5e-3
+        and f - c_te is nine ulps;
+    and a deviation beyond it must be explained by the reference's conditioning with respect to its INPUTS
+    (oracle/conditioning.py::misses_explained: within 16 x kappa x unit -- exponents of 40-60 in the step's exp2 double
+    the benchmark field's 8 --, kappa from central differences on the fp64 oracle; on a NaN edge the value must be one of
+    the outcomes the edge offers).  How many points may need more than the plain bar is limited: in the ATMOSPHERIC
+    REGION -- the reference's result 150 K <= tw <= 400 K and its step a correction, |step| <= 10 K (twice the largest
+    step on the benchmark distribution) -- ILL_CONDITIONED_FRACTION (1e-4) of the points; outside it twice the
+    reference's own fp32-vs-fp64 disagreements (fp64: twice the points whose rounding bound exceeds the plain bar).  Every count goes to the ledger.
+"""
+import numpy as np
+
+from _compare import CENSUS, ILL_CONDITIONED_FRACTION, _record, assert_parity, bisect_sign_noise, bisect_unstable, rel_err
+
+N_POINTS = 1 << 20
+SEED = 20261004
+PHYS = (150.0, 400.0)       # the reference's result is an atmospheric temperature ...
+STEP_FACTOR = 16.0          # how many roundings of that size may add up (the same allowance as for kappa below)
+KAPPA_FACTOR = 16.0         # measured on the host twin: <= 9.1
+MAX_STEP = 10.0             # ... and its Newton step a correction of the guess (benchmark distribution: <= 5.0 K)
+F64_ASSERT = 1e-7           # fp64 bar 1e-6; asserted one order inside it
+UNIT = {"f32": 2.0 ** -24, "f64": 2e-9}  # rounding unit of the arithmetic under test (fp64: the primitives' accuracy)
+
+METHODS = ("ifs", "bolton35", "bolton39")
+T_METHODS = ("bisect", "newton")
+FUNCS = (("temperature_on_moist_adiabat", ("ept", "p")),
+         ("wet_bulb_temperature_from_specific_humidity", ("t", "q", "p")))
+CASES = [(f, keys, m, tm) for f, keys in FUNCS for m in METHODS for tm in T_METHODS]
+
+
+def make(n=N_POINTS, seed=SEED, dtype=np.float32):
+    r = np.random.default_rng(seed)
+    d = dict(t=r.uniform(150.0, 400.0, n),
+             p=np.exp(r.uniform(np.log(1.0), np.log(1.26e5), n)),
+             q=np.exp(r.uniform(np.log(1e-7), np.log(0.9), n)),
+             ept=np.exp(r.uniform(np.log(150.0), np.log(3000.0), n)))
+    return {k: v.astype(dtype) for k, v in d.items()}
+
+
+def judge(func, keys, method, t_method, tag, d, got):
+    """Raises AssertionError on a real miss; returns the line that goes into the terminal summary."""
+    from oracle import conditioning
+    from oracle import thermo_oracle as orc
+
+    kwargs = dict(ept_method=method, t_method=t_method)
+    ins = [d[k] for k in keys]
+    ins64 = [a.astype(np.float64) for a in ins]
+    what = f"fuzz {func}[{method},{t_method},{tag}]"
+    f = getattr(orc, func)
+    with np.errstate(all="ignore"):
+        want = f(*ins, **kwargs)
+        ref64 = f(*ins64, **kwargs) if tag == "f32" else None
+    got = np.asarray(got).reshape(want.shape)
+    assert got.dtype == want.dtype, (what, got.dtype, want.dtype)
+    n = want.size
+    if t_method == "bisect":
+        unstable, noise_t = bisect_sign_noise(orc, func, ins, kwargs, 3e-6 if tag == "f32" else 1e-14, return_points=True)
+        if ref64 is not None:
+            unstable |= bisect_unstable(want, ref64)
+        worst = assert_parity(got, want, tag, what, bisect=True, unstable=unstable, ref64=ref64, noise_t=noise_t)
+        same = float(np.mean((got == want) | (np.isnan(got) & np.isnan(want))))
+        line = f"{what}: {n} points, {same:.5%} bit-identical, {int(unstable.sum())} reference-unstable (all anchored), worst stable {worst:.2e}"
+        CENSUS.append(line)
+        return line
+
+    tol = 1e-4 if tag == "f32" else F64_ASSERT
+    g64, w64 = got.astype(np.float64), want.astype(np.float64)
+    nanmm = np.isnan(g64) != np.isnan(w64)
+    r = rel_err(g64, w64)
+    bar = np.full(n, tol)
+    own = np.zeros(n, bool)  # the reference disagrees with itself beyond tol
+    if ref64 is not None:
+        delta = rel_err(w64, ref64)
+        own = delta > tol
+        bar = np.maximum(tol, 4.0 * delta)
+    # the operands of the reference's own Newton step, from the fp64 oracle
+    with np.errstate(all="ignore"):
+        e64 = ins64[0] if func == "temperature_on_moist_adiabat" else orc.ept_from_specific_humidity(*ins64, method=method)
+        e64, p64 = np.broadcast_arrays(e64, ins64[-1])
+        tw64, parts = orc._t_on_ma_newton(orc._EPT[method], e64.ravel().copy(), p64.ravel().copy(), return_parts=True)
+        guess = parts["guess"].reshape(w64.shape)
+        step = np.abs(guess - tw64.reshape(w64.shape))
+        phys = (w64 >= PHYS[0]) & (w64 <= PHYS[1]) & (step <= MAX_STEP)
+        # first-order rounding bound of the reference's own last line, tw = guess - (f - c_te)/(f*dlnf), every operand
+        # carrying roundings of its own size: the subtraction of guess and step; f - c_te over f*dlnf; dlnf = -lambda*(1/tw
+        # + ...) a sum that may cancel (its first term alone is lambda/guess); f = exp(ln f) evaluated at a rounded guess
+        # (d ln f / d tw by central difference on the oracle) through exponents of |ln f|, c_te likewise
+        af, ac, ad, at = (np.abs(parts[k]).reshape(w64.shape) for k in ("f", "c_te", "dlnf", "dlnf_true"))
+        at = np.where(np.isfinite(at), np.maximum(at, ad), ad)
+        cond = (np.abs(guess) + (af + ac) / (af * ad)
+                + step * ((orc.LAMBDA / np.abs(guess)) / ad + np.abs(guess) * at + np.abs(np.log(af)) + np.abs(np.log(ac)))) / np.abs(w64)
+    bar = np.where(np.isfinite(cond), np.maximum(bar, STEP_FACTOR * cond * UNIT[tag]), bar)
+    # beyond every bar: the reference's conditioning with respect to its inputs must explain it (kappa / NaN edges)
+    miss = nanmm | (r > bar)
+    idx = np.flatnonzero(miss)
+    if idx.size:
+        fin, edge = conditioning.misses_explained(lambda *x: f(*x, **kwargs), [a[idx] for a in ins64], g64[idx], w64[idx],
+                                                  tol, unit=UNIT[tag], factor=KAPPA_FACTOR)
+        ok = fin | edge
+        assert ok.all(), (f"{what}: {int((~ok).sum())} deviations that the reference's own conditioning does not explain, e.g. index "
+                          f"{idx[~ok][:4]} got {g64[idx][~ok][:4]} want {w64[idx][~ok][:4]} (atmospheric region: {phys[idx][~ok][:4]})")
+    # how many points needed more than the plain bar: few where the reference returns an atmospheric temperature ...
+    relaxed = nanmm | (r > tol)
+    rel_in = int((relaxed & phys).sum())
+    lim_in = max(3, ILL_CONDITIONED_FRACTION * int(phys.sum()))
+    _record(what, "newton: ill-conditioned points at max(rtol, 4*delta, the step's own conditioning)", rel_in, lim_in, int(phys.sum()))
+    assert rel_in <= lim_in, f"{what}: {rel_in} ill-conditioned points in the atmospheric region (limit {lim_in:.0f})"
+    # ... and elsewhere no more than the reference's own fp32-vs-fp64 disagreements, twice over
+    out = relaxed & ~phys
+    if ref64 is None:  # fp64 has no second reference: as many as the oracle's own rounding bound puts beyond the plain bar
+        own = bar > tol
+    lim_out = 2 * int((own & ~phys).sum()) + max(3, 1e-5 * n)
+    _record(what, "newton fuzz: points outside the atmospheric region (150 K <= tw <= 400 K, |step| <= 10 K) beyond the plain bar, all explained",
+            int(out.sum()), lim_out, int((~phys).sum()))
+    assert out.sum() <= lim_out, f"{what}: {int(out.sum())} relaxed points outside the atmospheric region (limit {lim_out:.0f})"
+    worst = float(r[phys & ~relaxed].max()) if (phys & ~relaxed).any() else 0.0
+    line = (f"{what}: {n} points, NaN mismatches {int(nanmm.sum())} (on the reference's own NaN edges), atmospheric region "
+            f"{int(phys.sum())} points worst {worst:.2e} ({rel_in} ill-conditioned beyond {tol:g}), outside it {int(out.sum())} beyond "
+            f"{tol:g} (the reference's own {'fp32-vs-fp64' if ref64 is not None else 'rounding bound beyond it'}: {int((own & ~phys).sum())}), unexplained 0")
+    CENSUS.append(line)
+    return line
