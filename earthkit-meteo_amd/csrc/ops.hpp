@@ -15,6 +15,9 @@
 #ifndef EKM_TREE_WAVES
 #define EKM_TREE_WAVES 6
 #endif
+#ifndef EKM_TREE_THREADS
+#define EKM_TREE_THREADS 512
+#endif
 #ifndef EKM_WAVES_PER_EU_DEFAULT
 #define EKM_WAVES_PER_EU_DEFAULT EKM_WAVES_PER_EU
 #endif
@@ -204,18 +207,19 @@ template <int METHOD>
 struct BisectTable {
   typedef BisectTable<METHOD> table_type;  // all ops of one theta_e method share one device-resident table
   static constexpr int elems = kBisectLattice;
+  static constexpr int method = METHOD;
   template <class T>
-  static constexpr int count() {
-    return sizeof(T) == 4 ? 3 * kHeapNodes : kBisectLattice + 3 * kHeapNodes / 2;  // fp64: es lattice, then the fp32 tree
+  static constexpr int count() {  // fp32: the tree (thermo_math.hpp::heap_rec floats per node); fp64: es lattice, then the fp32 tree
+    return sizeof(T) == 4 ? heap_rec<METHOD, float>() * kHeapNodes : kBisectLattice + heap_rec<METHOD, double>() * kHeapNodes / 2;
   }
   template <class T>
   EKM_HD static void fill(T* __restrict__ tab, int tid, int nthreads) {
     for (int m = tid; m < kBisectLattice; m += nthreads) {
       if constexpr (sizeof(T) == 4) {
-        bisect_heap_fill<METHOD>(tab, m);
+        bisect_heap_fill<METHOD, heap_rec<METHOD, float>()>(tab, m);
       } else {
         bisect_es_fill(tab, m);
-        bisect_heap_fill<METHOD>(reinterpret_cast<float*>(tab + kBisectLattice), m);
+        bisect_heap_fill<METHOD, heap_rec<METHOD, double>()>(reinterpret_cast<float*>(tab + kBisectLattice), m);
       }
     }
   }
@@ -452,12 +456,22 @@ struct OpUsesTie<OpPipelineFull> {
 // (with 256 threads three workgroups were 12 waves, and the search -- a chain of dependent LDS reads -- ran
 // latency-bound at 4.1 ms where the same instruction stream at five workgroups of a 32-KiB table took 3.4;
 // profiles/r04_bisect_tree_walk.txt), and its kernels are held to the 80 registers six waves per SIMD allow.
+template <class Op, bool TABLE = (OpTable<Op>::elems > 0)>
+struct OpTreeMethod {
+  static constexpr int value = -1;
+};
+template <class Op>
+struct OpTreeMethod<Op, true> {
+  static constexpr int value = OpTable<Op>::method;
+};
 template <class Op, class T>
 struct OpThreads {
   static constexpr bool tree = OpTable<Op>::elems > 0 && OpTable<Op>::vectorized;
-  static constexpr int value = tree ? 512 : EKM_THREADS_DEFAULT;
-  // fp32: 48 KiB, three workgroups = six waves per SIMD (<= 80 registers); fp64: 80 KiB, two workgroups = four waves
-  static constexpr int field_waves = tree ? (sizeof(T) == 4 ? EKM_TREE_WAVES : 4) : EKM_WAVES_PER_EU;
+  // the fp32 IFS walk with 16-B records: 64 KiB, two 1024-thread workgroups = eight waves per SIMD (<= 64 registers)
+  static constexpr bool wide = tree && sizeof(T) == 4 && OpTreeMethod<Op>::value == EPT_IFS && heap_rec<EPT_IFS, float>() == 4;
+  static constexpr int value = wide ? 1024 : tree ? EKM_TREE_THREADS : EKM_THREADS_DEFAULT;
+  // else fp32: 48 KiB, three workgroups = six waves per SIMD (<= 80 registers); fp64: 80 KiB, two workgroups = four waves
+  static constexpr int field_waves = wide ? 8 : tree ? (sizeof(T) == 4 ? EKM_TREE_WAVES : 4) : EKM_WAVES_PER_EU;
 };
 
 // Waves per SIMD a kernel of this op should be compiled for (launch bounds: caps the register allocation).

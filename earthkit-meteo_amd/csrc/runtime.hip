@@ -280,6 +280,7 @@ int ekm_device_count(void) {
 const char* ekm_last_error(void) { return g_err; }
 
 const char* ekm_version(void) { return "ekm_thermo 0.1.0 (gfx950)"; }
+int ekm_abi_version(void) { return EKM_ABI_VERSION; }
 
 int ekm_device_name(int dev, char* buf, size_t buflen) {
   int rc = use_device(dev);

@@ -813,33 +813,108 @@ EKM_HD void bisect_es_fill(double* __restrict__ tab, int m) { tab[m] = es_mixed(
 constexpr int kHeapNodes = kBisectLattice;
 constexpr double kHeapTau0 = 2.5e-6, kHeapTau1 = 1.2e-6;
 
+// Two layouts of the tree (REC = floats of table per node):
+//   3  4096 (es, a) pairs, then the 4096 L: 48 KiB, one ds_read_b64 + one ds_read_b32 per node (two address shifts);
+//   4  4096 records (es, a, L, t_m) of 16 B: 64 KiB, ONE ds_read_b128 per node (one shift, one LDS instruction less per
+//      step and point; t_m spares the exact branch the lattice arithmetic).  Two 1024-thread workgroups with 64 KiB each
+//      fill a CU with 8 waves per SIMD at <= 64 registers: the fp32 IFS walk (ops.hpp::OpThreads).  The Bolton walks need
+//      more registers than that and the fp64 walks carry the fp64 lattice beside the tree: both keep layout 3.
+#ifndef EKM_HEAP_REC_IFS
+#define EKM_HEAP_REC_IFS 4
+#endif
+#ifndef EKM_HEAP_B128
+#define EKM_HEAP_B128 1    // 1: the record in one ds_read_b128; 0: ds_read_b64 + ds_read_b32 from the one address (A/B:
+#endif                     // 3.32 against 3.21 ms; merged by the compiler into ONE ds_read_b96 when L sits right behind a: 3.73)
+#ifndef EKM_HEAP_L_SLOT
+#define EKM_HEAP_L_SLOT 3  // record = (es, a, t_m, L)
+#endif
+template <int METHOD, class T>
+constexpr int heap_rec() {
+  return (METHOD == EPT_IFS && sizeof(T) == 4) ? EKM_HEAP_REC_IFS : 3;
+}
+struct HeapNode {
+  float es, a, L;
+};
+template <int REC>
+EKM_HD HeapNode heap_read(const float* __restrict__ tab, unsigned node) {
+  HeapNode r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const char* __restrict__ base = reinterpret_cast<const char*>(tab);
+  if (REC == 4) {
+#if EKM_HEAP_B128
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = *reinterpret_cast<const f4*>(base + (node << 4));  // one ds_read_b128 (a register tuple of four per point)
+    r.es = v[0];
+    r.a = v[1];
+    r.L = v[EKM_HEAP_L_SLOT];
+#else
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const char* __restrict__ rec = base + (node << 4);  // ONE address: ds_read_b64 + ds_read_b32 offset:12
+    const f2 ea = *reinterpret_cast<const f2*>(rec);
+    r.es = ea[0];
+    r.a = ea[1];
+    r.L = *reinterpret_cast<const float*>(rec + 4 * EKM_HEAP_L_SLOT);
+#endif
+  } else {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 ea = *reinterpret_cast<const f2*>(base + (node << 3));  // one ds_read_b64
+    r.es = ea[0];
+    r.a = ea[1];
+    r.L = *reinterpret_cast<const float*>(base + 8 * kHeapNodes + (node << 2));
+  }
+#else
+  if (REC == 4) {
+    r.es = tab[4 * node];
+    r.a = tab[4 * node + 1];
+    r.L = tab[4 * node + EKM_HEAP_L_SLOT];
+  } else {
+    r.es = tab[2 * node];
+    r.a = tab[2 * node + 1];
+    r.L = tab[2 * kHeapNodes + node];
+  }
+#endif
+  return r;
+}
+template <int REC>
+EKM_HD float heap_es(const float* __restrict__ tab, unsigned node) {
+  return tab[(REC == 4 ? 4 : 2) * node];
+}
+
 // lattice index of heap node i at depth d (2^d <= i < 2^(d+1)), d <= 11
 EKM_HD int bisect_heap_lattice(int i, int d) { return (2 * (i - (1 << d)) + 1) << (11 - d); }
 
-template <int METHOD = EPT_IFS>
+template <int METHOD = EPT_IFS, int REC = 3>
 EKM_HD void bisect_heap_fill(float* __restrict__ tab, int i) {
-  float es = 0.0f, a = 0.0f, L = 0.0f;
+  float es = 0.0f, a = 0.0f, L = 0.0f, t = 0.0f;
   if (i >= 1) {
     int d = 0;
     while ((2 << d) <= i) ++d;
-    const float t = bisect_lattice_t<float>(bisect_heap_lattice(i, d));
+    t = bisect_lattice_t<float>(bisect_heap_lattice(i, d));
     es = es_mixed(t);
     a = bisect_second<METHOD>(es, 1.0f / t);  // IEEE division: once per device
     L = (float)m_log2(double(t) * (1.0 / 273.16));
   }
-  tab[2 * i] = es;
-  tab[2 * i + 1] = a;
-  tab[2 * kHeapNodes + i] = L;
+  if (REC == 4) {
+    tab[4 * i] = es;
+    tab[4 * i + 1] = a;
+    tab[4 * i + EKM_HEAP_L_SLOT] = L;
+    tab[4 * i + (5 - EKM_HEAP_L_SLOT)] = t;
+  } else {
+    tab[2 * i] = es;
+    tab[2 * i + 1] = a;
+    tab[2 * kHeapNodes + i] = L;
+  }
 }
 
-// heap child of `node` by the sign of the residual: 2*node + (r > 0) -- one compare and one add-with-carry
-EKM_HD unsigned bisect_heap_child(unsigned node, float r) {
+// heap child of `node` by the sign of the residual r: 2*node + (r > 0), from MINUS r (`nr`): ONE v_alignbit_b32 on the device,
+// the sign bit of -r shifted in behind the node index ({node, -r} >> 31); the sign tests below form -D directly.  (-r has
+// its sign bit set for r = +0 as well, where `r > 0` is false: a zero residual is always ambiguous, the exact branch then
+// records the node as the lane's answer and where the walk goes afterwards no longer matters; NaN likewise.)
+EKM_HD unsigned bisect_heap_child(unsigned node, float nr) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  unsigned next;
-  asm("v_cmp_lt_f32 vcc, 0, %2\n\tv_addc_co_u32 %0, vcc, %1, %1, vcc" : "=v"(next) : "v"(node), "v"(r) : "vcc");
-  return next;
+  return __builtin_amdgcn_alignbit(node, __builtin_bit_cast(unsigned, nr), 31u);
 #else
-  return node + node + (r > 0.0f ? 1u : 0u);
+  return (node << 1) | (__builtin_bit_cast(unsigned, nr) >> 31);
 #endif
 }
 
@@ -851,7 +926,7 @@ EKM_HD unsigned bisect_heap_child(unsigned node, float r) {
 //   bolton39  g = a_m*ws*(1 + 0.448*ws) + kappa*log2(v/p0)                           (thermo.py:1280-1295)
 //             g > u  <=>  D = a_m*eps*es_m*(v + 0.448*eps*es_m) + v^2*(kappa*log2(v/p0) - u) > 0   ONE log2 (of three)
 // with u = L_m - le, le = log2(theta_e/273.16) (`te` is theta_e itself for these methods; `kl` is read for bolton35 only).
-// D of one node (fp32): positive <=> the residual is positive, unless |D| <= the band (then `amb`).  w = the positive
+// D of one node (fp32): positive <=> the residual is positive, unless |D| <= the band (then `amb`); returned NEGATED.  w = the positive
 // denominator the exact step divides by (ifs: p + (eps-1)*es; Bolton: p - es); thr0 = the part of the band that goes with p.
 constexpr double kB35WsExact = 2.0;
 
@@ -869,50 +944,95 @@ EKM_HD T bisect_b35_residual(T te, T tm, T a, T ws, T kl) {
   return m_fms(te, m_exp2_denorm(a * ws), tm * m_exp2_denorm(kl * m_fms(T(0.28), ws, T(1))));
 }
 
+// The reference's residual at one lattice node, theta_e*exp(G_sat(scale=-1)) - th_sat (thermo.py:1075), as the stepwise search
+// evaluates it (operation for operation the same in the tree walk's exact branch and in bisect_exact_walk): for ifs and
+// bolton39 divided by the positive th_sat/t_m -- r = te*2^g - t_m --, for bolton35 as it stands (bisect_b35_residual).
+// w = the denominator of the step (ifs: p + (eps-1)*es; Bolton: p - es).
 template <int METHOD>
+EKM_HD float bisect_exact_residual(float es, float a, float w, float te, float tm, float kl) {
+  if (METHOD == EPT_BOLTON35) return bisect_b35_residual(te, tm, a, float(k::eps) * es * m_rcp(w), kl);
+  float g;
+  if (METHOD == EPT_IFS) {
+    g = a * m_rcp(w);
+  } else {
+    const float ws = float(k::eps) * es * m_rcp(w);
+    g = m_fma(a * ws, m_fma(0.448f, ws, 1.0f), float(k::kappa) * m_log2(w * float(1.0 / k::p0)));
+  }
+  return m_fms(te, METHOD == EPT_IFS ? m_exp2(g) : m_exp2_denorm(g), tm);
+}
+
+// WS: test ws >= kB35WsExact at every node (the fp64 walk); the fp32 walk asks once, of the hottest node it visited
+template <int METHOD, bool WS = true>
 EKM_HD float bisect_fast_test(float es, float a, float u, float p, float kl, float& w, float thr0, bool& amb) {
-  float D, scale;  // scale: |a_m| resp. its counterpart -- the part of the band that goes with the size of the exponent
-  bool big_ws = false;
+  float D, scale;  // D: MINUS the quantity of the comments above (bisect_heap_child takes it so); scale: |a_m| resp. its
+  bool big_ws = false;  // counterpart -- the part of the band that goes with the size of the exponent
   if (METHOD == EPT_IFS) {
     w = m_fma(float(k::eps - 1), es, p);
-    D = m_fnma(u, w, a);
+    D = m_fms(u, w, a);
     scale = a;
   } else if (METHOD == EPT_BOLTON35) {
     w = p - es;
     const float ees = float(k::eps) * es;
     scale = ees * m_fnma(0.28f, kl, a);
-    D = m_fma(kl - u, w, scale);
+    D = m_fms(u - kl, w, scale);
     // ws = eps*es/(p - es) >= kB35WsExact: the reference's two terms, theta_e*exp(-2675*ws/t) and th_sat =
     // t*(p0/p)^(kappa*(1 - 0.28*ws)), can BOTH leave the normal range there (ws of several hundred where p - es is a
     // fraction of a pascal: 0 - 0, sign 0, the reference stays on this node for good), and D -- the residual divided
     // by th_sat/t -- no longer says what the reference's own subtraction gives.  Below the limit both terms are
     // normal numbers (|exponents| <= 29*2 resp. 47*1.56) and the division changes nothing.  Decided by the exact step.
-    big_ws = !(w > float(kB35WsExact) * ees);
+    if (WS) big_ws = !(w > float(kB35WsExact) * ees);
   } else {
     w = p - es;
     const float ees = float(k::eps) * es;
     scale = (a * ees) * m_fma(0.448f, ees, w);
     const float v2 = w * w;
-    D = m_fma(v2, m_fms(float(k::kappa), m_log2(w * float(1.0 / k::p0)), u), scale);
+    D = m_fms(v2, m_fnma(float(k::kappa), m_log2(w * float(1.0 / k::p0)), u), scale);
     thr0 = float(2.0 * kHeapTau0) * v2;  // the band in units of v^2 here (log2 of a small v adds its own rounding)
   }
   amb = !(__builtin_fabsf(D) > m_fma(__builtin_fabsf(scale), float(METHOD == EPT_IFS ? kHeapTau1 : 2.0 * kHeapTau1), thr0));  // NaN: ambiguous
-  if (METHOD == EPT_BOLTON35) amb = amb || big_ws;
+  if (METHOD == EPT_BOLTON35 && WS) amb = amb || big_ws;
   return D;
+}
+
+// The stepwise search itself on the fp32 tree, one point, every step the reference's own residual -- rolled up (it runs for
+// the rare points the tree walk hands back, below), the same operations as the walk's exact branch: with `all_exact` the
+// walk returns these bits.
+template <int METHOD>
+EKM_HD float bisect_exact_walk(float te, float p, float kl, const float* __restrict__ tab) {
+  constexpr int REC = heap_rec<METHOD, float>();
+  unsigned node = 1u;
+  float tfix = 0.0f, esmax = 0.0f;
+#pragma unroll 1
+  for (int d = 0; d < 12; ++d) {
+    const HeapNode nd = heap_read<REC>(tab, node);
+    const float es = nd.es, a = nd.a;
+    const float w = METHOD == EPT_IFS ? m_fma(float(k::eps - 1), es, p) : p - es;
+    const float tm = bisect_lattice_t<float>(bisect_heap_lattice((int)node, d));
+    const float r = bisect_exact_residual<METHOD>(es, a, w, te, tm, kl);
+    if (tfix == 0.0f) {
+      esmax = m_max(esmax, es);
+      if (!(r < 0.0f || r > 0.0f)) tfix = r == 0.0f ? tm : r;
+    }
+    node = bisect_heap_child(node, -r);
+  }
+  float t = float(k::T0 - 20) + float(2 * (int)node - (3 * kHeapNodes - 1)) * float(120.0 / 4096);
+  if (tfix != 0.0f) t = tfix;
+  if ((p - esmax) < float(k::eps_default)) t = nan_v<float>();
+  return t;
 }
 
 template <int METHOD, int V>
 EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], const float (&p)[V], const float (&kl)[V],
                                 const float* __restrict__ tab, float (&out)[V], bool all_exact = false) {
-  // esmax: the largest es visited, kept as its bit pattern -- the table's es are finite and >= 0, so their bit patterns
-  // order like the values and the running maximum is ONE v_max_u32 (v_max_f32 wants a canonicalising copy of a freshly
-  // loaded operand in front of it)
-  unsigned node[V], esmax[V], esfix[V];
+  // The largest es visited (for the NaN rule) is not tracked step by step: es grows with t, so it is es of the HOTTEST node
+  // visited -- the first node the walk left downwards, or the deepest one if it never did -- and the heap index of every
+  // visited node is a prefix of the leaf's (node at depth d = leaf >> (12 - d)): one count-leading-zeros on the inverted
+  // path and ONE table read at the end instead of a running maximum in every step (two registers per point less, too).
+  unsigned node[V];
   float thr0[V], tfix[V], lq[V];  // tfix: the final answer of a lane whose residual came out exactly zero or NaN; 0 = none yet
 #pragma unroll
   for (int j = 0; j < V; ++j) {
     node[j] = 1u;
-    esmax[j] = esfix[j] = 0u;
     thr0[j] = float(kHeapTau0) * p[j];
     // an infinite theta_e (fp32 overflow of its exponential for q of 0.8) times an exp(G_sat) that underflowed is NaN in the
     // reference where the logarithmic test reads +inf: with a NaN logarithm every test of such a point is NaN, i.e.
@@ -920,28 +1040,25 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
     lq[j] = (METHOD != EPT_IFS && !(lte[j] < std::numeric_limits<float>::infinity())) ? nan_v<float>() : lte[j];
     tfix[j] = 0.0f;
   }
-  const char* __restrict__ pairs = reinterpret_cast<const char*>(tab);
-  const char* __restrict__ logs = pairs + 8 * kHeapNodes;
+  constexpr int REC = heap_rec<METHOD, float>();
 #pragma unroll
   for (int d = 0; d < 12; ++d) {
-    float es[V], a[V], w[V], D[V];
+    float es[V], a[V], w[V], D[V], L[V];
     bool amb[V];
     unsigned long long any = 0ull;  // lanes of the wave with an ambiguous test at this depth, over the V points
+    // (forcing all table reads of a step out before the first is waited for -- the compiler pairs the points, two LDS
+    // round trips per step -- changes nothing: profiles/r05_tree_walk.txt)
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-#if defined(__HIP_DEVICE_COMPILE__)
-      typedef float f2 __attribute__((ext_vector_type(2)));
-      const f2 ea = *reinterpret_cast<const f2*>(pairs + (node[j] << 3));  // one ds_read_b64
-      es[j] = ea[0];
-      a[j] = ea[1];
-#else
-      es[j] = tab[2 * node[j]];
-      a[j] = tab[2 * node[j] + 1];
-#endif
-      const float u = *reinterpret_cast<const float*>(logs + (node[j] << 2)) - lq[j];
-      D[j] = bisect_fast_test<METHOD>(es[j], a[j], u, p[j], kl[j], w[j], thr0[j], amb[j]);
-      const unsigned eb = __builtin_bit_cast(unsigned, es[j]);
-      esmax[j] = esmax[j] > eb ? esmax[j] : eb;
+      const HeapNode nd = heap_read<REC>(tab, node[j]);
+      es[j] = nd.es;
+      a[j] = nd.a;
+      L[j] = nd.L;
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float u = L[j] - lq[j];
+      D[j] = bisect_fast_test<METHOD, false>(es[j], a[j], u, p[j], kl[j], w[j], thr0[j], amb[j]);
       any |= EKM_WAVE_MASK(amb[j]);
       amb[j] = amb[j] || all_exact;
     }
@@ -950,23 +1067,10 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
       for (int j = 0; j < V; ++j) {
         if (amb[j]) {
           const float tm = bisect_lattice_t<float>(bisect_heap_lattice((int)node[j], d));
-          float r;  // the stepwise search's step (above), operation for operation
-          if (METHOD == EPT_BOLTON35) {
-            r = bisect_b35_residual(te[j], tm, a[j], float(k::eps) * es[j] * m_rcp(w[j]), kl[j]);
-          } else {
-            float g;
-            if (METHOD == EPT_IFS) {
-              g = a[j] * m_rcp(w[j]);
-            } else {
-              const float ws = float(k::eps) * es[j] * m_rcp(w[j]);
-              g = m_fma(a[j] * ws, m_fma(0.448f, ws, 1.0f), float(k::kappa) * m_log2(w[j] * float(1.0 / k::p0)));
-            }
-            r = m_fms(te[j], METHOD == EPT_IFS ? m_exp2(g) : m_exp2_denorm(g), tm);
-          }
-          D[j] = r;
+          const float r = bisect_exact_residual<METHOD>(es[j], a[j], w[j], te[j], tm, kl[j]);  // the stepwise search's step
+          D[j] = -r;
           if (!(r < 0.0f || r > 0.0f) && tfix[j] == 0.0f) {  // zero: the reference stays on this point; NaN: it turns NaN
             tfix[j] = r == 0.0f ? tm : r;  // (lattice temperatures are >= 133 K: never the "none" value)
-            esfix[j] = esmax[j];
           }
         }
       }
@@ -979,12 +1083,38 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
     // the leaf (4096 <= node < 8192): t0 + (M - 4096)*120/4096 with M = 2*(node - 4096) + 1, i.e. 2*node - 12287 half
     // steps from t0 -- exactly the reference's accumulated fp32 sum
     float t = float(k::T0 - 20) + float(2 * (int)node[j] - (3 * kHeapNodes - 1)) * float(120.0 / 4096);
-    unsigned em = esmax[j];
-    if (tfix[j] != 0.0f) {
-      t = tfix[j];
-      em = esfix[j];
+    // hottest node visited: decisions of depths 0 .. 10 are bits 11 .. 1 of the leaf index; the first 0 among them
+    const unsigned inv = ~node[j] & 0xFFEu;
+    unsigned dmax = (inv ? (unsigned)__builtin_clz(inv) : 32u) - 20u;
+    dmax = dmax < 11u ? dmax : 11u;
+    unsigned nmax = node[j] >> (12u - dmax);
+    if (EKM_ANY(tfix[j] != 0.0f)) {  // (rare, wave-uniform) a search that got stuck at depth k visited depths 0 .. k only
+      if (tfix[j] != 0.0f) {
+        t = tfix[j];
+        if (t == t) {  // the stuck temperature is a lattice point: its depth is 11 - (trailing zeros of its lattice index)
+          const unsigned m = (unsigned)(int)__builtin_rintf((t - float(k::T0 - 20)) * float(2048.0 / 120.0)) + 2048u;
+          const unsigned kf = 11u - (unsigned)__builtin_ctz(m | 2048u);
+          const unsigned invk = inv & ~((1u << (12u - kf)) - 1u);
+          dmax = invk ? (unsigned)__builtin_clz(invk) - 20u : kf;
+          nmax = node[j] >> (12u - dmax);
+        }
+      }
     }
-    if ((p[j] - __builtin_bit_cast(float, em)) < float(k::eps_default)) t = nan_v<float>();
+    const float esmax = heap_es<REC>(tab, nmax);
+    if ((p[j] - esmax) < float(k::eps_default)) t = nan_v<float>();
+    if (METHOD == EPT_BOLTON35) {
+      // ws = eps*es/(p - es) >= kB35WsExact at the hottest node visited (ws grows with es): the reference's two terms, theta_e*
+      // exp(-2675*ws/t) and th_sat = t*(p0/p)^(kappa*(1 - 0.28*ws)), can BOTH leave the normal range there (ws of several
+      // hundred where p - es is a fraction of a pascal: 0 - 0, sign 0, the reference stays on that node for good), and the
+      // sign test -- the residual divided by th_sat/t -- no longer says what the reference's own subtraction gives.  Below
+      // the limit both terms are normal numbers (|exponents| <= 29*2 resp. 47*1.56) and the division changes nothing.  The
+      // walk agrees with the stepwise search up to the first such node, which is therefore ON its path: asked once per
+      // point, here, and such a point (never an atmospheric one) is searched again step by step.
+      const bool suspect = !((p[j] - esmax) > float(k::eps / kB35WsExact) * esmax) && !all_exact;
+      if (EKM_ANY(suspect)) {
+        if (suspect) t = bisect_exact_walk<METHOD>(te[j], p[j], kl[j], tab);
+      }
+    }
     out[j] = t;
   }
 }
@@ -1016,8 +1146,7 @@ EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (
     if (METHOD != EPT_IFS && !(ltef[j] < std::numeric_limits<float>::infinity())) ltef[j] = nan_v<float>();  // as in the fp32 walk
     tfix[j] = T(0.0);
   }
-  const char* __restrict__ pairs = reinterpret_cast<const char*>(heap);
-  const char* __restrict__ logs = pairs + 8 * kHeapNodes;
+  constexpr int REC = heap_rec<METHOD, double>();
 #pragma unroll
   for (int d = 0; d < 12; ++d) {
     float D[V];
@@ -1025,14 +1154,9 @@ EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (
     unsigned long long any = 0ull;  // lanes of the wave with an ambiguous test at this depth, over the V points
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-#if defined(__HIP_DEVICE_COMPILE__)
-      typedef float f2 __attribute__((ext_vector_type(2)));
-      const f2 ea = *reinterpret_cast<const f2*>(pairs + (node[j] << 3));
-      const float es = ea[0], a = ea[1];
-#else
-      const float es = heap[2 * node[j]], a = heap[2 * node[j] + 1];
-#endif
-      const float u = *reinterpret_cast<const float*>(logs + (node[j] << 2)) - ltef[j];
+      const HeapNode nd = heap_read<REC>(heap, node[j]);
+      const float es = nd.es, a = nd.a;
+      const float u = nd.L - ltef[j];
       float w;
       D[j] = bisect_fast_test<METHOD>(es, a, u, pf[j], klf[j], w, thr0[j], amb[j]);  // (the band is wide enough for the
       any |= EKM_WAVE_MASK(amb[j]);                                                  //  inputs' rounding to float)
@@ -1061,7 +1185,7 @@ EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (
             }
             r = m_fms(te[j], METHOD == EPT_IFS ? m_exp2(g) : m_exp2_denorm(g), tm);
           }
-          D[j] = r > T(0) ? 1.0f : -1.0f;
+          D[j] = r > T(0) ? -1.0f : 1.0f;
           if (!(r < T(0) || r > T(0)) && kfix[j] < 0) {
             kfix[j] = d;
             tfix[j] = r == T(0) ? tm : r;

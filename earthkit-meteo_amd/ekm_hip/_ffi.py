@@ -11,6 +11,7 @@ import threading
 from ._optable import OPS
 
 EKM_OK = 0
+ABI_VERSION = 5  # include/ekm_thermo.h: EKM_ABI_VERSION (tests/test_abi.py keeps the two equal)
 EKM_ERR_HIP, EKM_ERR_ARG, EKM_ERR_ENUM, EKM_ERR_NODEV = -1, -2, -3, -4
 FIELD, SCALAR, LEVEL_MAJOR, LEVEL_MINOR, HYBRID_FULL = 0, 1, 2, 3, 4
 
@@ -49,7 +50,7 @@ def _signatures():
     pvp = C.POINTER(C.c_void_p)
     sig = {
         "ekm_init": ([], i), "ekm_device_count": ([], i),
-        "ekm_last_error": ([], C.c_char_p), "ekm_version": ([], C.c_char_p),
+        "ekm_last_error": ([], C.c_char_p), "ekm_version": ([], C.c_char_p), "ekm_abi_version": ([], i),
         "ekm_device_name": ([i, C.c_char_p, sz], i), "ekm_device_cus": ([i], i),
         "ekm_mem_info": ([i, C.POINTER(sz), C.POINTER(sz)], i),
         "ekm_malloc": ([i, sz, pvp], i), "ekm_free": ([i, vp], i),
@@ -110,6 +111,17 @@ def lib():
                     handle = C.CDLL(path)
                 except OSError as exc:
                     raise EkmLibraryError(f"cannot load {path}: {exc}") from exc
+                # the ABI version first: a library of another round fails here with a sentence, not with an
+                # AttributeError on whichever symbol happens to be missing
+                try:
+                    handle.ekm_abi_version.restype = C.c_int
+                    have = handle.ekm_abi_version()
+                except AttributeError:
+                    have = None
+                if have != ABI_VERSION:
+                    raise EkmLibraryError(f"{path} has ABI version {have if have is not None else '< 5 (no ekm_abi_version)'}, this "
+                                          f"binding needs {ABI_VERSION} (include/ekm_thermo.h: EKM_ABI_VERSION): rebuild with "
+                                          "`make -C earthkit-meteo_amd`")
                 for name, (args, res) in _signatures().items():
                     fn = getattr(handle, name)  # AttributeError here = header/library mismatch
                     fn.argtypes = args

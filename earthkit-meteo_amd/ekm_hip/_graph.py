@@ -18,7 +18,11 @@ HIP call:
 Rules: every array operand inside the block is a DeviceArray, because uploads cannot be recorded (a Python scalar is fine:
 its value is written by a recorded fill and is a constant of the graph; a 0-d DeviceArray is a scalar that can change
 between launches); results hold no data until the first `launch()`; the graph keeps every array it touches alive
-(and their addresses fixed) until `close()`.  The reference has no counterpart: its functions run eagerly on the host."""
+(and their addresses fixed) until `close()` -- a tensor of another library taken over with `ekm_hip.from_dlpack` BEFORE
+the block included: its deleter runs after `close()`.  What that library does to such a tensor between launches runs on
+streams this package does not know: synchronise it (`torch.cuda.synchronize()`) before `launch()`.  One thread records
+and launches a graph: work another thread submits on another stream, on an array of the block, after the block began
+is ordered before the first `launch()` only.  The reference has no counterpart: its functions run eagerly on the host."""
 import ctypes as C
 
 from . import _ffi

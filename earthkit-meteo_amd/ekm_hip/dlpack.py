@@ -10,7 +10,7 @@ import numpy as np
 
 import threading
 
-from .device import DeviceArray, _no_capture, _register_owner, current_device, current_stream, order_streams
+from .device import DeviceArray, _capturing, _no_capture, _register_owner, current_device, current_stream, order_streams
 
 kDLROCM = 10
 kDLFloat = 2
@@ -91,16 +91,30 @@ class _Borrowed:
 
     def __init__(self, managed, device, stream):
         self.managed, self.device, self.stream = managed, device, stream
+        self.pins, self.free_pending = 0, False  # recorded graphs that hold this memory's address (ekm_hip.graph)
         self._lock = threading.Lock()
         _register_owner(self)
 
     def touch(self, stream):
+        cap = _capturing()
+        if cap is not None:
+            # recording (as device._Allocation.touch): the graph pins the tensor -- the producer's deleter runs only after
+            # Graph.close() -- and orders itself after our other uses of it at every launch; no event is recorded on a
+            # capturing stream.  What the PRODUCER does to the tensor between launches is on streams we do not know:
+            # synchronise the producer before Graph.launch() (documented there).
+            cap._adopt(self)
+            with self._lock:
+                self.stream = stream
+            return
         with self._lock:
             if stream != self.stream:
                 order_streams(self.device, self.stream, stream)
                 self.stream = stream
 
     def free(self):
+        if self.pins:  # a recorded graph still launches kernels on this address: released when the graph is closed
+            self.free_pending = True
+            return
         m, self.managed = self.managed, None
         if m is not None and m.deleter:
             # the producer may reuse the memory as soon as its deleter has run: our work on it must be complete

@@ -140,6 +140,31 @@ ek.set_stream(None)
 ref = ek.thermo.saturation_vapour_pressure(ek.to_device(big.cpu().numpy())).to_host()
 assert np.array_equal(got, ref), "stream hand-over lost ordering"
 
+# a torch tensor taken over BEFORE an ekm_hip.graph() block, used as an operand inside it (the route _graph.py and the
+# `_adopt_foreign` message recommend): the recording stream gets no event, the graph pins the borrowed tensor (its deleter
+# waits for close()), and a replay after torch has changed the tensor in place computes on the new contents
+gt = torch.rand(1 << 20, device=dev) * 60.0 + 240.0
+gp = torch.full((1 << 20,), 85000.0, device=dev)
+torch.cuda.synchronize()
+bt, bp = ek.from_dlpack(gt), ek.from_dlpack(gp)
+with ek.graph() as g:
+    gth = ek.thermo.potential_temperature(bt, bp)
+owner = bt._alloc
+assert owner.pins == 1, "the graph did not adopt the borrowed tensor"
+for rnd in range(3):
+    gt.mul_(1.0 + 0.01 * rnd).add_(0.5)   # torch mutates the operand in place, on its own stream
+    torch.cuda.synchronize()               # (documented: synchronise the producer before launch)
+    g.launch().synchronize()
+    eager = ek.thermo.potential_temperature(ek.to_device(gt.cpu().numpy()), ek.to_device(gp.cpu().numpy())).to_host()
+    assert np.array_equal(gth.to_host(), eager), f"graph replay {rnd} on a DLPack operand differs from the eager call"
+bt.free()                                  # released while the graph still holds the address: the deleter must wait
+assert owner.free_pending and owner.managed is not None, "a pinned borrowed tensor was released under a live graph"
+g.launch().synchronize()
+g.close()
+assert owner.managed is None, "the producer's deleter did not run after Graph.close()"
+del bt, bp, gth, owner
+print("graph with DLPack operands: 4 replays across in-place torch updates, deleter deferred until close()")
+
 # rejections
 for bad, exc in ((torch.ones(4), TypeError), (torch.ones(4, dtype=torch.int32, device=dev), TypeError),
                  (torch.ones(4, 4, device=dev).t(), ValueError)):

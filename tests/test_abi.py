@@ -43,6 +43,37 @@ def test_library_exports_every_declared_symbol():
     assert _ffi.lib().ekm_version().decode().startswith("ekm_thermo")
 
 
+def test_abi_version_of_header_binding_and_library_agree():
+    """removed entry points and changed meanings must be visible as a version, checked at load time."""
+    import re
+
+    from ekm_hip import _ffi
+
+    in_header = int(re.search(r"#define EKM_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert in_header == _ffi.ABI_VERSION == _ffi.lib().ekm_abi_version()
+
+
+def test_a_library_of_another_abi_version_is_refused_with_a_sentence(tmp_path, monkeypatch):
+    import subprocess
+
+    from ekm_hip import _ffi
+
+    src = tmp_path / "old.c"
+    src.write_text("int ekm_abi_version(void) { return 4; }\n")
+    old = tmp_path / "libold.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(old), str(src)], check=True)
+    monkeypatch.setenv("EKM_THERMO_LIB", str(old))
+    monkeypatch.setattr(_ffi, "_lib", None)
+    with pytest.raises(_ffi.EkmLibraryError, match="ABI version 4.*needs 5"):
+        _ffi.lib()
+    none = tmp_path / "libnone.so"
+    src.write_text("int something_else(void) { return 0; }\n")
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(none), str(src)], check=True)
+    monkeypatch.setenv("EKM_THERMO_LIB", str(none))
+    with pytest.raises(_ffi.EkmLibraryError, match="no ekm_abi_version"):
+        _ffi.lib()
+
+
 def test_no_torch_on_the_product_path():
     import subprocess
     import sys

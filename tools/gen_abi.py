@@ -155,7 +155,7 @@ extern "C" {
 
 typedef struct ekm_operand {
   const void* data; /* device pointer (float* for _f32, double* for _f64)         */
-  int32_t mode;     /* EKM_FIELD / EKM_SCALAR / EKM_LEVEL_MAJOR / EKM_LEVEL_MINOR */
+  int32_t mode;     /* one of the five: EKM_FIELD / _SCALAR / _LEVEL_MAJOR / _LEVEL_MINOR / _HYBRID_FULL */
   int32_t nflat;    /* EKM_HYBRID_FULL: number of LEADING levels k with B[k] = B[k+1] = 0 (pure pressure
                        levels: the upper 53 of the 137 IFS levels), which then run at level-vector
                        speed in a launch of their own; 0 is always valid.  Else 0.            */
@@ -164,6 +164,16 @@ typedef struct ekm_operand {
   const void* aux0; /* EKM_HYBRID_FULL: A table (device), else NULL                */
   const void* aux1; /* EKM_HYBRID_FULL: B table (device), else NULL                */
 } ekm_operand;
+
+/* ---- ABI version ----
+ * Bumped whenever an exported symbol is removed or changes its signature or meaning (history: INTEGRATION.md).  A client
+ * built against this header compares EKM_ABI_VERSION with ekm_abi_version() of the library it loaded before any
+ * other call (ekm_hip/_ffi.py does); a library older than version 5 does not export the function at all.
+ *   5  (round 5) ekm_abi_version added.  Since round 3 (unnumbered "4"): ekm_copy_staged, ekm_host_memcpy,
+ *      ekm_host_register, ekm_host_unregister removed; "table_tiles" default 8 -> 0 (= by op); field pointers must be
+ *      aligned to their element size; at most 32 KiB (was 64) of staged level vectors per launch. */
+#define EKM_ABI_VERSION 5
+EKM_API int ekm_abi_version(void);              /* EKM_ABI_VERSION of the library as built */
 
 /* ---- lifecycle ---- */
 EKM_API int ekm_init(void);                     /* probes the HIP runtime; EKM_ERR_NODEV without a GPU */
