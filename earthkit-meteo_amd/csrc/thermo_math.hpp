@@ -1067,7 +1067,10 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
       for (int j = 0; j < V; ++j) {
         if (amb[j]) {
           const float tm = bisect_lattice_t<float>(bisect_heap_lattice((int)node[j], d));
-          const float r = bisect_exact_residual<METHOD>(es[j], a[j], w[j], te[j], tm, kl[j]);  // the stepwise search's step
+          // ifs: te itself is needed here only -- it is formed from its logarithm, which the sign tests carry anyway (one
+          // exp2 per point less on the common path, and no register for it)
+          const float tej = METHOD == EPT_IFS ? 273.16f * m_exp2(lq[j]) : te[j];
+          const float r = bisect_exact_residual<METHOD>(es[j], a[j], w[j], tej, tm, kl[j]);  // the stepwise search's step
           D[j] = -r;
           if (!(r < 0.0f || r > 0.0f) && tfix[j] == 0.0f) {  // zero: the reference stays on this point; NaN: it turns NaN
             tfix[j] = r == 0.0f ? tm : r;  // (lattice temperatures are >= 133 K: never the "none" value)

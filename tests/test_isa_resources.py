@@ -74,26 +74,33 @@ TREE = re.compile(r"(7OpTOnMa|15OpWetBulbFromTd|14OpWetBulbFromQ|12OpWbptFromTd|
 
 
 def test_no_kernel_of_the_built_library_runs_out_of_registers(built_kernels):
-    """Scratch memory = registers spilled: nowhere, except 12 B per lane in two bolton35 tree-walk kernels, spilled once at
-    kernel entry (the lane's first element index, reloaded for the ragged tail), outside the tile loop."""
-    allowed = re.compile(r"map_fieldsINS_1[45]OpWetBulbFrom(Q|Td)ILi1ELi0EEEfLi1E")
+    """Scratch memory = registers spilled: nowhere, except 12 B per lane in full-field tree-walk kernels from three inputs
+    (bolton35; the fp32 IFS walk at its 64-register cap), spilled once at kernel entry (the lane's first element index,
+    reloaded for the ragged tail), outside the tile loop."""
+    allowed = re.compile(r"map_fieldsINS_1[1245]Op(WetBulb|Wbpt)From(Q|Td)ILi[01]ELi0EEEfLi1E")
     bad = {k: v for k, v in built_kernels.items() if v["scratch"] > (12 if allowed.search(k) else 0)}
     assert not bad, bad
 
 
 def test_tree_walk_kernels_keep_their_occupancy(built_kernels):
-    """512 threads around one copy of the tree: fp32 48 KiB and <= 80 registers (three workgroups = six waves per SIMD),
-    fp64 80 KiB and <= 128 registers (two workgroups = four waves per SIMD); no two-tile or level-walk instantiation."""
+    """One copy of the tree per workgroup.  fp32 IFS walk (round 5): 1024 threads around 64 KiB of 16-B records and <= 64
+    registers (two workgroups = eight waves per SIMD); fp32 Bolton walks: 512 threads, 48 KiB, <= 80 registers (three
+    workgroups = six waves per SIMD); fp64: 512 threads, 80 KiB, <= 128 registers (two workgroups = four waves per SIMD);
+    no two-tile or level-walk instantiation."""
     tree = {k: v for k, v in built_kernels.items() if TREE.search(k) and ("map_fields" in k or "map_levels" in k or "map_bcast" in k)}
     assert len(tree) == 2 * 15 * 5, len(tree)   # map_fields, map_bcast, map_levels x (level vector, flat, hybrid)
+    wide = 0
     for k, v in tree.items():
         f64 = re.search(r"EEEd(Li|EE)", k) is not None
-        assert v["threads"] == 512, (k, v)
-        assert v["lds"] == ((80 if f64 else 48) << 10), (k, v)
+        ifs32 = not f64 and re.search(r"ILi0ELi0EEE", k) is not None
+        wide += ifs32
+        assert v["threads"] == (1024 if ifs32 else 512), (k, v)
+        assert v["lds"] == ((80 if f64 else 64 if ifs32 else 48) << 10), (k, v)
         if "map_bcast" not in k:
-            assert v["vgpr"] <= (128 if f64 else 80), (k, v)
+            assert v["vgpr"] <= (128 if f64 else 64 if ifs32 else 80), (k, v)
         assert not re.search(r"map_fields.*Li2EEEv", k), k                      # UNROLL = 2
         assert not re.search(r"map_levels.*Li\dELb1EEEv", k), k                 # WALK
+    assert wide == 5 * 5, wide
 
 
 def test_six_output_pipeline_kernels_of_the_built_library(built_kernels):
