@@ -434,7 +434,7 @@ def main():
     sync()
     dist.barrier()
     sync()
-    t0 = time.perf_counter()
+    t0 = time.perf_counter()  # CLOCK_MONOTONIC: one clock for every process of the node, so the ranks' stamps compare
     for k in range(args.steps):
         if not args.dry_run:
             _ffi.check(lib.ekm_event_record(dev, evs[k], None))  # same (default) stream the kernels are launched on
@@ -442,10 +442,16 @@ def main():
     if not args.dry_run:
         _ffi.check(lib.ekm_event_record(dev, evs[-1], None))
     sync()
-    elapsed = time.perf_counter() - t0  # this rank's K steps, from the common start to its own device sync
+    t1 = time.perf_counter()
+    elapsed = t1 - t0                   # this rank's K steps, from the common start to its own device sync
     dist.barrier()                      # the closing bracket: nobody reports before everybody has finished
     sync()
     elapsed = dist.reduce(elapsed, "max")  # the job took as long as its slowest rank
+    # how much of the timed region is the barrier's exit skew (at N = 8 a strong-scaling step is ~0.7 ms and the whole
+    # region ~13 ms): the spread of the ranks' own start stamps, and of their end stamps
+    stamps = dist.gather([t0, t1])
+    barrier_skew_ms = (max(v[0] for v in stamps) - min(v[0] for v in stamps)) * 1e3
+    end_skew_ms = (max(v[1] for v in stamps) - min(v[1] for v in stamps)) * 1e3
 
     ndev_seen, dev_used, my_ms = -1, -1, float("nan")
     sustained = None
@@ -616,6 +622,9 @@ def main():
             "roofline": roof, "sustained": sustained, "cpu_baseline": cpu, "parity": parity,
             "parity_last_rank": parity_last, "shard_window_last_rank": shard_window,
             "hip_device_count": ndev_min, "devices_used": devices, "oversubscribed": oversub,
+            # `value` = points x steps / timed_region; barrier_skew_ms = latest minus earliest start stamp of the ranks
+            # (one monotonic clock per node): the part of the region that is the barrier's exit skew, not GPU time
+            "timed_region_ms": round(elapsed * 1e3, 4), "barrier_skew_ms": round(barrier_skew_ms, 4), "end_skew_ms": round(end_skew_ms, 4),
         }
         if kernel_ms:
             # `value` is the metric: points x steps / wall time between the barriers (slowest rank).  Beside it the same

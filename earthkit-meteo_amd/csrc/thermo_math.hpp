@@ -151,11 +151,12 @@ EKM_HD float m_pow(float x, float y) { return std::pow(x, y); }
 // fp64 on gfx950: there is no fp64 transcendental unit and the device libm pays for correctly rounded
 // results (pow alone is ~200 instructions).  Measured issue cost (tools/microbench/valu_rates_f64.hip):
 // v_fma_f64 5.2 clk per wave, v_rcp_f64 17 clk.  The parity bar for fp64 is 1e-6 relative, so by default
-// the three primitives are built to ~1e-10 (four orders inside the bar; the GPU tests assert <= 1e-9 against the
-// reference's fp64 goldens):
+// the three primitives are built to ~2e-9 (the GPU tests assert <= 1e-7 against the reference's fp64 goldens, one order
+// inside the bar; raw v_rcp_f64 is 4.6e-8 -- tools/microbench/f64_seed_accuracy.hip -- and its error would be multiplied
+// by exponents of up to 40 in es, so the reciprocal keeps its Newton step):
 //   rcp  = v_rcp_f64 seed + ONE Newton step (<= 1e-14);
-//   exp2 = round-to-nearest split + degree-7 near-minimax polynomial of 2^f, ln 2 folded in + v_ldexp_f64 (4.0e-11);
-//   log2 = v_frexp + 2*atanh(s), s = (m-1)/(m+1), as s*q(s^2) with a degree-4 near-minimax q (4.2e-12);
+//   exp2 = round-to-nearest split + degree-6 minimax polynomial of 2^f, ln 2 folded in + v_ldexp_f64 (1.9e-9);
+//   log2 = v_frexp + 2*atanh(s), s = (m-1)/(m+1), as s*q(s^2) with a degree-3 minimax q (6.9e-10);
 //   pow  = exp2(y*log2(x)).
 // -DEKM_F64_EXACT selects the <= 3e-16 versions (two Newton steps, degree-12 Taylor, atanh series to s^21)
 // for A/B comparison.  inf / 0 / NaN behave as in libm in both.
@@ -221,6 +222,10 @@ EKM_HD double m_log2(double x) {
 // each one with two v_mov_b32 in front of a v_fmac_f64 (122 v_mov per point in the six-output pipeline, ~10 % of its
 // issue time; profiles/r03).  Read through the scalar cache they are SGPR pairs, loaded once per wave, that
 // v_fma_f64 takes directly as its addend.  (static: one copy per translation unit / device module.)
+// Round 5: one degree less in each polynomial (exp2 degree 6: 1.9e-9, atanh degree 3: 6.9e-10; round 4: degree 7 / 4,
+// 4.0e-11 / 4.2e-12).  The bar is 1e-6; with these the six outputs of the pipeline stay below 1e-8 of the reference
+// (asserted <= 1e-7).  -DEKM_F64_R4_POLY keeps round 4's.
+#if defined(EKM_F64_R4_POLY)
 static __constant__ double kF64Coef[16] = {
     // 2^f on |f| <= 0.5, degree 7, near-minimax in relative error (4.0e-11), ln 2 folded in; ascending
     0.9999999999616818, 0.693147180728452, 0.24022651198156714, 0.05550410353429554, 0.009618027253757476,
@@ -228,28 +233,44 @@ static __constant__ double kF64Coef[16] = {
     // atanh(s)/s on z = s^2 in [0, 0.0295], degree 4 (4.2e-12); ascending
     1.0000000000041798, 0.3333333262373743, 0.20000192337193154, 0.14267525468490147, 0.1180818033212343,
     0.0, 0.0, 0.0};
-#if defined(EKM_F64_COEF_LITERAL)
-#define EKM_F64C(i, lit) (lit)
 #else
-#define EKM_F64C(i, lit) (kF64Coef[i])
+static __constant__ double kF64Coef[16] = {
+    // 2^f on |f| <= 0.5, degree 6, minimax in relative error (1.86e-9), ln 2 folded in; ascending
+    1.0000000005541665, 0.6931472057372673, 0.2402264689063404, 0.05550328776965614, 0.00961848895713086,
+    0.0013399931219141663, 0.0001534581199765244, 0.0,
+    // atanh(s)/s on z = s^2 in [0, 0.0295], degree 3, minimax in relative error (6.9e-10); ascending
+    0.9999999993106649, 0.3333340797542721, 0.19987397462507944, 0.14962825347475195, 0.0,
+    0.0, 0.0, 0.0};
 #endif
+#if defined(EKM_F64_COEF_LITERAL)
+#error "EKM_F64_COEF_LITERAL was a round-3 A/B switch; the coefficients live in constant memory"
+#endif
+#define EKM_F64C(i) (kF64Coef[i])
 EKM_HD double exp2_poly(double f) {  // 2^f, |f| <= 0.5
-  double p = EKM_F64C(7, 1.5201918192496034e-05);
-  p = __builtin_fma(p, f, EKM_F64C(6, 0.00015469291117256424));
-  p = __builtin_fma(p, f, EKM_F64C(5, 0.0013333922578355431));
-  p = __builtin_fma(p, f, EKM_F64C(4, 0.009618027253757476));
-  p = __builtin_fma(p, f, EKM_F64C(3, 0.05550410353429554));
-  p = __builtin_fma(p, f, EKM_F64C(2, 0.24022651198156714));
-  p = __builtin_fma(p, f, EKM_F64C(1, 0.693147180728452));
-  p = __builtin_fma(p, f, EKM_F64C(0, 0.9999999999616818));
+#if defined(EKM_F64_R4_POLY)
+  double p = EKM_F64C(7);
+  p = __builtin_fma(p, f, EKM_F64C(6));
+#else
+  double p = EKM_F64C(6);
+#endif
+  p = __builtin_fma(p, f, EKM_F64C(5));
+  p = __builtin_fma(p, f, EKM_F64C(4));
+  p = __builtin_fma(p, f, EKM_F64C(3));
+  p = __builtin_fma(p, f, EKM_F64C(2));
+  p = __builtin_fma(p, f, EKM_F64C(1));
+  p = __builtin_fma(p, f, EKM_F64C(0));
   return p;
 }
 EKM_HD double atanh_poly(double z) {  // atanh(s)/s, z = s^2
-  double p = EKM_F64C(12, 0.1180818033212343);
-  p = __builtin_fma(p, z, EKM_F64C(11, 0.14267525468490147));
-  p = __builtin_fma(p, z, EKM_F64C(10, 0.20000192337193154));
-  p = __builtin_fma(p, z, EKM_F64C(9, 0.3333333262373743));
-  p = __builtin_fma(p, z, EKM_F64C(8, 1.0000000000041798));
+#if defined(EKM_F64_R4_POLY)
+  double p = EKM_F64C(12);
+  p = __builtin_fma(p, z, EKM_F64C(11));
+#else
+  double p = EKM_F64C(11);
+#endif
+  p = __builtin_fma(p, z, EKM_F64C(10));
+  p = __builtin_fma(p, z, EKM_F64C(9));
+  p = __builtin_fma(p, z, EKM_F64C(8));
   return p;
 }
 // v_cvt_i32_f64 saturates (+-2^31, NaN -> 0); the C cast is undefined out of range
@@ -961,8 +982,8 @@ EKM_HD float bisect_exact_residual(float es, float a, float w, float te, float t
   return m_fms(te, METHOD == EPT_IFS ? m_exp2(g) : m_exp2_denorm(g), tm);
 }
 
-// WS: test ws >= kB35WsExact at every node (the fp64 walk); the fp32 walk asks once, of the hottest node it visited
-template <int METHOD, bool WS = true>
+// WS: test ws >= kB35WsExact at every node (A/B only: both walks ask once, of the hottest node they visited)
+template <int METHOD, bool WS = false>
 EKM_HD float bisect_fast_test(float es, float a, float u, float p, float kl, float& w, float thr0, bool& amb) {
   float D, scale;  // D: MINUS the quantity of the comments above (bisect_heap_child takes it so); scale: |a_m| resp. its
   bool big_ws = false;  // counterpart -- the part of the band that goes with the size of the exponent
@@ -1130,6 +1151,50 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
 // nine orders below it), so outside it the fp32 sign IS the sign of the fp64 residual.
 // Largest es visited (the NaN rule): es grows with t, so it is es of the hottest node visited -- the first node the
 // walk left DOWNWARDS, or the deepest node if it never did -- read once at the end from the fp64 table.
+// the stepwise search's step in T at lattice point m (es from the fp64 lattice table), operation for operation the same in
+// the walk's exact branch and in bisect_exact_walk64: 1/(v*t) gives both 1/v and 1/t
+template <int METHOD, class T>
+EKM_HD T bisect_exact_residual64(T es, T tm, T te, T p, T kl) {
+  const T v = METHOD == EPT_IFS ? m_fma(T(k::eps - 1), es, p) : p - es;
+  const T r1 = m_rcp(v * tm);
+  const T rv = r1 * tm, a = bisect_second<METHOD>(es, r1 * v);
+  if (METHOD == EPT_BOLTON35) return bisect_b35_residual(te, tm, a, T(k::eps) * es * rv, kl);
+  T g;
+  if (METHOD == EPT_IFS) {
+    g = a * rv;
+  } else {
+    const T ws = T(k::eps) * es * rv;
+    g = m_fma(a * ws, m_fma(T(0.448), ws, T(1)), T(k::kappa) * m_log2(v * T(1.0 / k::p0)));
+  }
+  return m_fms(te, METHOD == EPT_IFS ? m_exp2(g) : m_exp2_denorm(g), tm);
+}
+
+// the stepwise search in T, one point, rolled up (for the rare points the fp64 walk hands back; bisect_exact_walk's twin)
+template <int METHOD, class T>
+EKM_HD T bisect_exact_walk64(T te, T p, T kl, const T* __restrict__ es_tab) {
+  unsigned node = 1u;
+  bool fixed = false;
+  T tfix = T(0.0), esmax = T(0.0);
+#pragma unroll 1
+  for (int d = 0; d < 12; ++d) {
+    const int m = bisect_heap_lattice((int)node, d);
+    const T tm = bisect_lattice_t<T>(m), es = es_tab[m];
+    const T r = bisect_exact_residual64<METHOD>(es, tm, te, p, kl);
+    if (!fixed) {
+      esmax = m_max(esmax, es);
+      if (!(r < T(0) || r > T(0))) {
+        fixed = true;
+        tfix = r == T(0) ? tm : r;
+      }
+    }
+    node = bisect_heap_child(node, r > T(0) ? -1.0f : 1.0f);
+  }
+  T t = T(k::T0 - 20) + T(2 * (int)node - (3 * kHeapNodes - 1)) * T(120.0 / 4096);
+  if (fixed) t = tfix;
+  if ((p - esmax) < T(k::eps_default)) t = nan_v<T>();
+  return t;
+}
+
 template <int METHOD, class T, int V>
 EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (&p)[V], const T (&kl)[V],
                                   const float* __restrict__ heap, const T* __restrict__ es_tab, T (&out)[V],
@@ -1161,8 +1226,8 @@ EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (
       const float es = nd.es, a = nd.a;
       const float u = nd.L - ltef[j];
       float w;
-      D[j] = bisect_fast_test<METHOD>(es, a, u, pf[j], klf[j], w, thr0[j], amb[j]);  // (the band is wide enough for the
-      any |= EKM_WAVE_MASK(amb[j]);                                                  //  inputs' rounding to float)
+      D[j] = bisect_fast_test<METHOD, false>(es, a, u, pf[j], klf[j], w, thr0[j], amb[j]);  // (the band is wide enough for
+      any |= EKM_WAVE_MASK(amb[j]);                                                         //  the inputs' rounding to float)
       amb[j] = amb[j] || all_exact;
     }
     if (any != 0ull || all_exact) {
@@ -1170,24 +1235,8 @@ EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (
       for (int j = 0; j < V; ++j) {
         if (amb[j]) {
           const int m = bisect_heap_lattice((int)node[j], d);
-          const T tm = bisect_lattice_t<T>(m), es = es_tab[m];
-          // the stepwise search's step in T, operation for operation: 1/(v*t) gives both 1/v and 1/t
-          const T v = METHOD == EPT_IFS ? m_fma(T(k::eps - 1), es, p[j]) : p[j] - es;
-          const T r1 = m_rcp(v * tm);
-          const T rv = r1 * tm, a = bisect_second<METHOD>(es, r1 * v);
-          T r;
-          if (METHOD == EPT_BOLTON35) {
-            r = bisect_b35_residual(te[j], tm, a, T(k::eps) * es * rv, kl[j]);
-          } else {
-            T g;
-            if (METHOD == EPT_IFS) {
-              g = a * rv;
-            } else {
-              const T ws = T(k::eps) * es * rv;
-              g = m_fma(a * ws, m_fma(T(0.448), ws, T(1)), T(k::kappa) * m_log2(v * T(1.0 / k::p0)));
-            }
-            r = m_fms(te[j], METHOD == EPT_IFS ? m_exp2(g) : m_exp2_denorm(g), tm);
-          }
+          const T tm = bisect_lattice_t<T>(m);
+          const T r = bisect_exact_residual64<METHOD>(es_tab[m], tm, te[j], p[j], kl[j]);
           D[j] = r > T(0) ? -1.0f : 1.0f;
           if (!(r < T(0) || r > T(0)) && kfix[j] < 0) {
             kfix[j] = d;
@@ -1202,18 +1251,22 @@ EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (
 #pragma unroll
   for (int j = 0; j < V; ++j) {
     T t = T(k::T0 - 20) + T(2 * (int)node[j] - (3 * kHeapNodes - 1)) * T(120.0 / 4096);
-    // hottest node visited: among the nodes of depth 0 .. last (last = 11, or the step the search got stuck at), the
-    // first one left downwards (a 0 bit of the path), else the node of depth `last`
-    const int last = kfix[j] >= 0 ? kfix[j] : 11;
-    const unsigned path = node[j] & (unsigned)(kHeapNodes - 1);  // the 12 decisions, the first one in bit 11
-    int dmax = last;
-#pragma unroll
-    for (int d = 11; d >= 0; --d)
-      if (d < last && !((path >> (11 - d)) & 1u)) dmax = d;
-    const unsigned nmax = (1u << dmax) | (path >> (12 - dmax));
-    const T esmax = es_tab[bisect_heap_lattice((int)nmax, dmax)];
+    // hottest node visited (as in the fp32 walk): among the nodes of depth 0 .. last (last = 11, or the step the search
+    // got stuck at), the first one left downwards -- decisions of depths 0 .. 10 are bits 11 .. 1 of the leaf index --,
+    // else the node of depth `last`; a visited node's heap index is a prefix of the leaf's
+    const unsigned last = kfix[j] >= 0 ? (unsigned)kfix[j] : 11u;
+    const unsigned inv = ~node[j] & 0xFFEu & ~((1u << (12u - last)) - 1u);
+    const unsigned dmax = inv ? (unsigned)__builtin_clz(inv) - 20u : last;
+    const unsigned nmax = node[j] >> (12u - dmax);
+    const T esmax = es_tab[bisect_heap_lattice((int)nmax, (int)dmax)];
     if (kfix[j] >= 0) t = tfix[j];
     if ((p[j] - esmax) < T(k::eps_default)) t = nan_v<T>();
+    if (METHOD == EPT_BOLTON35) {  // ws >= kB35WsExact at the hottest node visited: searched again step by step (see the fp32 walk)
+      const bool suspect = !((p[j] - esmax) > T(k::eps / kB35WsExact) * esmax) && !all_exact;
+      if (EKM_ANY(suspect)) {
+        if (suspect) t = bisect_exact_walk64<METHOD, T>(te[j], p[j], kl[j], es_tab);
+      }
+    }
     out[j] = t;
   }
 }

@@ -33,6 +33,9 @@ def _run_ranks(world, *extra):
     d = json.loads(lines[0])
     assert d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 1
     assert d["dry_run"] is True and d["value"] is None  # a dry run never reports a throughput
+    # the stamps of every rank reach rank 0: the region between the barriers, and how far apart the ranks left the first
+    assert d["timed_region_ms"] > 0 and d["barrier_skew_ms"] >= 0 and d["end_skew_ms"] >= 0
+    assert d["barrier_skew_ms"] < 5000, d  # gloo ranks of one host leave a barrier within seconds of one another
     return d
 
 

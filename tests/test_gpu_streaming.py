@@ -297,6 +297,9 @@ def test_bench_two_ranks_strong_scaling_on_one_device(ek, extra, cut):
     d = _run_two_ranks(ek, extra)
     nlev, inner = 16, 1800 * 3600
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["value_from_kernel_ms"] > 0
+    # the timed region and how much of it is the barrier's exit skew: value = points x steps / region
+    assert d["timed_region_ms"] > 0 and 0 <= d["barrier_skew_ms"] < d["timed_region_ms"] and d["end_skew_ms"] >= 0
+    assert abs(d["value"] - d["config"]["points_total"] * d["steps"] / (d["timed_region_ms"] * 1e-3)) <= 1e-3 * d["value"]
     assert d["config"]["shard_cut"] == cut
     assert d["oversubscribed"] == (ek.device_count() < 2) and d["hip_device_count"] == ek.device_count()
     assert d["parity"]["ok"] and d["parity"]["nan_mismatch"] == 0
