@@ -50,9 +50,9 @@ static int host_map(const T* const* ins, T* const* outs, size_t n, double rp) {
         } else {
           Op::template apply<ekm::fdouble>(xf, yf, ekm::fdouble(rp));
         }
-        bool finite = true;
-        for (int k = 0; k < Op::NOUT; ++k) finite = finite && std::isfinite(yf[k].v);
-        if (finite) {
+        double yv[Op::NOUT];
+        for (int k = 0; k < Op::NOUT; ++k) yv[k] = yf[k].v;
+        if (!ekm::two_pass_redo_needed<Op>(x, yv)) {  // every output finite, or non-finite because an input it depends on is NaN
           for (int k = 0; k < Op::NOUT; ++k) outs[k][i] = yf[k].v;
           continue;
         }

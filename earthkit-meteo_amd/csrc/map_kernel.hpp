@@ -186,7 +186,16 @@ __device__ __forceinline__ void apply_points(const T (&x)[V][Op::NIN], T (&y)[V]
         fin = gap < fin ? gap : fin;
       }
     }
-    const bool redo = fin == 0u || (switches & 1) != 0;  // f64_plain (tuning parameter, wave-uniform): every lane takes the plain pass
+    bool redo = fin == 0u;
+    if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
+      // (rare, wave-uniform) a non-finite output that a NaN INPUT explains needs no plain pass: ops.hpp::OpDeps
+      if (redo) {
+        redo = false;
+#pragma unroll
+        for (int j = 0; j < V; ++j) redo = redo || two_pass_redo_needed<Op>(x[j], y[j]);
+      }
+    }
+    redo = redo || (switches & 1) != 0;  // f64_plain (tuning parameter, wave-uniform): every lane takes the plain pass
     if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
       if (redo) {
         // one copy of the plain-double body, the point picked by selects: indexing x[j] / y[j] with a loop counter

@@ -451,6 +451,43 @@ struct OpUsesTie<OpPipelineFull> {
   static constexpr bool value = true;
 };
 
+// ---- fp64 two-pass kernels: which non-finite outputs of the fast pass need the plain pass ---------------------------
+// The fast pass (fdouble) poisons to NaN where a plain primitive would have fixed up an IEEE special operand, so a point
+// with a non-finite fast output is redone in plain double (map_kernel.hpp::apply_points).  NOT needed where the output
+// is non-finite because an INPUT it depends on is NaN -- a missing value, a masked land / sea point: NaN goes through
+// every formula of thermo_math.hpp (none drops it in a select or a min / max), so the plain pass returns NaN there too
+// and the fast pass's NaN stands.  Without this rule every masked point sent its whole wave through the serial plain
+// pass (fp64 kernels on a masked field cost more than twice a clean one; tools/f64_nan_rate.py).
+// OpDeps<Op>::of(o): bit i set = output o depends on input i.  Default: every output on every input.
+template <class Op>
+struct OpDeps {
+  static constexpr unsigned of(int) { return (1u << Op::NIN) - 1u; }
+};
+template <>
+struct OpDeps<OpPipelineSvpTdRh> {  // inputs (t, q, p): es(t), td(q, p), rh(t, q, p)
+  static constexpr unsigned of(int o) { return o == 0 ? 1u : o == 1 ? 6u : 7u; }
+};
+template <>
+struct OpDeps<OpPipelineFull> {  // theta(t, p), es(t), rh(t, q, p), td(q, p), theta_e(t, q, p), tw(t, q, p)
+  static constexpr unsigned of(int o) { return o == 0 ? 5u : o == 1 ? 1u : o == 3 ? 6u : 7u; }
+};
+template <int M>
+struct OpDeps<OpLcl<M>> {  // inputs (t, td, p): t_lcl(t, td), p_lcl(t, td, p)
+  static constexpr unsigned of(int o) { return o == 0 ? 3u : 7u; }
+};
+
+// one point: is there a non-finite output that no NaN input explains?  (x, y: the point's inputs and fast-pass outputs)
+template <class Op>
+EKM_HD bool two_pass_redo_needed(const double* __restrict__ x, const double* __restrict__ y) {
+  unsigned nan_in = 0u;
+#pragma unroll
+  for (int i = 0; i < Op::NIN; ++i) nan_in |= (x[i] != x[i] ? 1u : 0u) << i;
+  bool need = false;
+#pragma unroll
+  for (int o = 0; o < Op::NOUT; ++o) need = need || (!__builtin_isfinite(y[o]) && !(nan_in & OpDeps<Op>::of(o)));
+  return need;
+}
+
 // Threads per workgroup of an op's map kernels, and the waves per SIMD its kernels are compiled for.  The fp32 IFS
 // bisection keeps a 48-KiB search tree in LDS: 512 threads share one copy, so that three workgroups = 24 waves fit a CU
 // (with 256 threads three workgroups were 12 waves, and the search -- a chain of dependent LDS reads -- ran

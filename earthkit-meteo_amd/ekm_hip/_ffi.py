@@ -118,12 +118,20 @@ def lib():
                     have = handle.ekm_abi_version()
                 except AttributeError:
                     have = None
-                if have != ABI_VERSION:
+                # EKM_THERMO_LIB_ANY_ABI=1 (A/B tools only, together with EKM_THERMO_LIB): load a library of another round
+                # anyway; a symbol it lacks then fails at its first use
+                any_abi = os.environ.get("EKM_THERMO_LIB_ANY_ABI") == "1" and os.environ.get("EKM_THERMO_LIB")
+                if have != ABI_VERSION and not any_abi:
                     raise EkmLibraryError(f"{path} has ABI version {have if have is not None else '< 5 (no ekm_abi_version)'}, this "
                                           f"binding needs {ABI_VERSION} (include/ekm_thermo.h: EKM_ABI_VERSION): rebuild with "
                                           "`make -C earthkit-meteo_amd`")
                 for name, (args, res) in _signatures().items():
-                    fn = getattr(handle, name)  # AttributeError here = header/library mismatch
+                    try:
+                        fn = getattr(handle, name)  # AttributeError here = header/library mismatch
+                    except AttributeError:
+                        if any_abi:
+                            continue
+                        raise
                     fn.argtypes = args
                     fn.restype = res
                 _lib = handle
