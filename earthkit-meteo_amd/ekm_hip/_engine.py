@@ -20,7 +20,7 @@ import numpy as np
 
 from . import _ffi
 from ._optable import OPS
-from .device import DeviceArray, _capturing, current_device, current_stream
+from .device import DeviceArray, _capturing, _no_capture, current_device, current_stream
 from .vertical import HybridPressure
 
 _F32, _F64 = np.dtype(np.float32), np.dtype(np.float64)
@@ -306,13 +306,16 @@ def _run(name, args, ints, eps, dtype):
 # ordinary arrays, prefaulted from a helper thread.  A result in pooled memory does not own its data (`.base` is a ctypes
 # buffer; `ndarray.resize` refuses): EKM_PINNED_RESULTS=0 turns the pool off.
 _PINNED_OUT = os.environ.get("EKM_PINNED_RESULTS", "1") != "0"
-_PINNED_OUT_BYTES = int(os.environ.get("EKM_PINNED_RESULTS_BYTES", os.environ.get("EKM_PINNED_CACHE_BYTES", str(2 << 30))))
+# a call's results go to the pinned pool only if the pool would KEEP them afterwards: the per-call limit is the cache limit
+from .device import _pinned as _pinned_pool  # noqa: E402
+
+_PINNED_OUT_BYTES = int(os.environ.get("EKM_PINNED_RESULTS_BYTES", str(_pinned_pool.limit)))
 
 
 class _Pending:
     """One submitted launch: device results (and the temporaries its operands live in) not yet collected."""
 
-    __slots__ = ("plan", "results", "temps", "host_out", "internal_out", "toucher", "stream")
+    __slots__ = ("plan", "results", "temps", "host_out", "internal_out", "toucher", "stream", "keep")
 
 
 def _reserved(nbytes, reserve_rows):
@@ -341,6 +344,7 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
     fn = getattr(lib, f"ekm_{name}_{tag}")
 
     temps = []  # device buffers owned by this call
+    keep = []   # host arrays an upload still reads from (kept until the results are collected)
     operands = []
     lds_bytes = 0
     internal_out = False  # host_out allocated here (compute dtype) rather than supplied by the caller
@@ -401,7 +405,14 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
                 cls = (_ffi.FIELD, 0, 0)
             hc = np.ascontiguousarray(h, dtype=plan.dtype)
             cap = _reserved(hc.size * plan.dtype.itemsize, reserve_rows)
-            darr = DeviceArray.from_host(hc, device=dev, capacity=cap)
+            # the upload is queued, not waited for: from pageable memory the call returns once the data is staged, from
+            # pinned memory (ekm_hip.pinned_empty) at once -- the operands of a call go up back to back, the kernel follows
+            # on the same stream, and the one host wait is the download's (`hc` stays alive until then)
+            _no_capture("an upload (a NumPy operand)")
+            darr = DeviceArray.empty(hc.shape, hc.dtype, dev, capacity=cap)
+            if hc.nbytes:
+                _ffi.check(lib.ekm_h2d(dev, darr.on(stream), hc.ctypes.data, hc.nbytes, stream))
+            keep.append(hc)
             temps.append(darr)
         # .on(stream): an input last used on another stream makes this stream wait for that work (device-side)
         operands.append(_ffi.Operand(darr.on(stream), cls[0], 0, cls[1], cls[2]))
@@ -424,16 +435,21 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
             _recipes[key] = rec
     pend = _Pending()
     pend.plan, pend.results, pend.temps, pend.host_out = plan, results, temps, host_out
-    pend.internal_out, pend.toucher, pend.stream = internal_out, toucher, stream
+    pend.internal_out, pend.toucher, pend.stream, pend.keep = internal_out, toucher, stream, keep
     return pend
 
 
-def _collect(pend):
-    """Results of a submitted launch: DeviceArrays as they are, NumPy results downloaded on the CURRENT stream
-    (which must be the stream the launch was submitted on)."""
+def _collect(pend, refile=None):
+    """Results of a submitted launch: DeviceArrays as they are, NumPy results downloaded on the CURRENT stream -- the
+    stream the launch was submitted on, or another one (`DeviceArray.on` orders it behind the kernel on the device).
+    `refile`: the stream whose block cache the result blocks go back to (the streamed path downloads on a stream of its
+    own and hands the blocks back to the lane that will take them again; the download has completed on the host by then)."""
     plan, results, temps, host_out = pend.plan, pend.results, pend.temps, pend.host_out
     internal_out, toucher = pend.internal_out, pend.toucher
     if plan.on_device:
+        if pend.keep:  # a NumPy operand among DeviceArrays: its upload must have left the host array before we let go of it
+            _ffi.check(_ffi.lib().ekm_stream_sync(plan.device, pend.stream))
+            pend.keep = None
         # temporaries are freed by HIP in stream order after the kernel has run
         for t in temps:
             t.free()
@@ -442,14 +458,19 @@ def _collect(pend):
     if toucher is not None:
         toucher.join()
     host = []
+    # the downloads of a call are queued back to back and waited for ONCE
+    direct = [host_out is not None and host_out[k].dtype == plan.dtype and host_out[k].flags.c_contiguous for k in range(len(results))]
+    staged = [r.to_host(out=host_out[k] if direct[k] else None, sync=False) for k, r in enumerate(results)]
+    if results:
+        _ffi.check(_ffi.lib().ekm_stream_sync(plan.device, current_stream()))
+    pend.keep = None
     for k, r in enumerate(results):
-        if host_out is not None and host_out[k].dtype == plan.dtype and host_out[k].flags.c_contiguous:
-            h = r.to_host(out=host_out[k])  # straight into the caller's slice
-        else:
-            h = r.to_host()  # synchronises the stream
-            if host_out is not None:
-                host_out[k][...] = h
-                h = host_out[k]
+        h = staged[k]
+        if not direct[k] and host_out is not None:
+            host_out[k][...] = h
+            h = host_out[k]
+        if refile is not None:
+            r._alloc.stream = refile  # (the copies have been waited for: nothing is pending on the block)
         r.free()
         if plan.out_dtype != plan.dtype and (host_out is None or internal_out):
             h = h.astype(plan.out_dtype)

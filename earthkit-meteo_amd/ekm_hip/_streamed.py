@@ -33,7 +33,8 @@ _BLOCK_OVERHEAD = 1 << 20  # worst-case rounding of one device block (the alloca
 
 
 def _lane_stream(dev, slot):
-    """One long-lived stream per (device, lane slot 0.._MAX_LANES-1); `release_streams()` destroys them."""
+    """One long-lived stream per (device, lane slot 0.._MAX_LANES-1) plus one per device for the downloads (slot
+    "download"); `release_streams()` destroys them."""
     from .device import stream_create
 
     with _streams_lock:
@@ -107,9 +108,13 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
     * several GPUs (`multi_gpu()`): one contiguous block of rows per GPU (~17 whole levels each for
       [137, lat, lon] fields on 8 GPUs), no exchange of any kind;
     * per GPU: an uploader thread (slice k: upload its operands, launch, hand over) and a downloader thread (slice
-      k: download its results, free its device blocks) with `lanes` slices resident between them, each on the
-      stream (device, k mod lanes): exactly one upload and one download are in flight at a time -- PCIe is full
-      duplex, but concurrent pageable uploads collapse -- and the kernels run under both; a collected slice's
+      k: download its results, free its device blocks) with `lanes` slices resident between them, uploads and
+      kernels on the stream (device, k mod lanes), downloads on ONE stream of their own: exactly one upload and one
+      download are in flight at a time -- PCIe is full duplex, but concurrent pageable uploads collapse -- and the
+      kernels run under both.  (The download stream matters: HIP binds a stream to a DMA engine at its first copy, every
+      lane stream's first copy is an upload, and downloads issued on the lane streams shared that one engine with the
+      next slice's upload -- 29 + 29 GB/s where the link does 54 + 47 in both directions at once; round 5,
+      profiles/r05_host_path_rate.txt); a collected slice's
       device blocks go back to the block cache of its stream and are taken again `lanes` slices later, so the
       device working set is lanes x slice, chosen to fit `stream_budget_bytes` (fields larger than HBM stream
       through; with a tight budget this degrades to two resident slices, i.e. double buffering)."""
@@ -196,8 +201,11 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
                 part = [h[lo:hi] if sp else a for h, a, sp in zip(host, args, spans)]
                 # slices differ by one row: every slice's device blocks are sized for the LONGEST slice, so a lane takes
                 # back exactly the blocks it released (same bucket) and the footprint stays lanes x slice, live + cached
-                handoff.put(((lo, hi), _submit(name, part, ints, eps, dtype, host_out=[o[lo:hi] for o in outs],
-                                               reserve_rows=(hi - lo, most))))
+                pend = _submit(name, part, ints, eps, dtype, host_out=[o[lo:hi] for o in outs], reserve_rows=(hi - lo, most))
+                # ONE slice's uploads in flight: from pinned inputs they are asynchronous, and the uploads of several lanes
+                # queued at once share the link badly (P3 from pinned inputs: 60 GB/s against 77 with this wait)
+                _ffi.check(_ffi.lib().ekm_stream_sync(dev, pend.stream))
+                handoff.put(((lo, hi), pend))
                 if trace is not None:
                     trace.append(("up", k, t0, t1, _time.perf_counter()))
         except BaseException as exc:  # surfaced in the calling thread
@@ -220,8 +228,8 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
                         t0 = _time.perf_counter()
                         ready[sl].wait()
                         t1 = _time.perf_counter()
-                        set_stream(pend.stream)
-                        _collect(pend)
+                        set_stream(_lane_stream(dev, "download"))
+                        _collect(pend, refile=pend.stream)
                         if trace is not None:
                             trace.append(("down", sl[0], t0, t1, _time.perf_counter()))
                 finally:

@@ -253,6 +253,10 @@ def memory_stats(dev=None, reset_peak=False):
     with _cache.lock:
         out = {"live_bytes": _cache.live.get(dev, 0), "peak_live_bytes": _cache.peak.get(dev, 0),
                "cached_bytes": _cache.bytes.get(dev, 0), "peak_footprint_bytes": _cache.peak_total.get(dev, 0)}
+        pool = globals().get("_pinned")
+        if pool is not None:  # the pool of pinned HOST blocks (results of big NumPy calls): its bounds and its use
+            out["pinned"] = {"cache_limit_bytes": pool.limit, "live_limit_bytes": pool.live_limit,
+                             "cached_bytes": pool.cached, "live_bytes": pool.handed_out}
         if reset_peak:
             _cache.peak[dev] = _cache.live.get(dev, 0)
             _cache.peak_total[dev] = _cache.live.get(dev, 0) + _cache.bytes.get(dev, 0)
@@ -501,17 +505,34 @@ class _PinnedPool:
     faults and none of the pin / unpin work the runtime does around every copy into pageable memory.  hipHostMalloc is
     slow (it pins page by page), so blocks are recycled: the NumPy array handed to the caller keeps its block alive
     through a finalizer, and when the caller drops the array (and every view of it) the block comes back here.
-    Page-locked memory cannot be swapped and counts against container / memlock limits, so the pool is small by
-    default: once the callers hold EKM_PINNED_LIVE_BYTES (default 4 GiB) of pinned results alive, further results are
-    ordinary pageable arrays, and at most EKM_PINNED_CACHE_BYTES (default 2 GiB) of dropped blocks stay cached, the rest
-    is freed at once (`ekm_hip.empty_cache()` frees the cached ones too).  An array in pooled memory does not own its
-    data: `.base` is a ctypes buffer and `ndarray.resize` refuses."""
+    Page-locked memory cannot be swapped and counts against container / memlock limits, so the pool is BOUNDED, and its
+    bound comes from the machine (round 4's constant 2 GiB sent the 5 GB of results of a 32-level six-output call to
+    pageable arrays: 54 GB/s instead of 70): blocks held by callers plus blocks cached never exceed
+    EKM_PINNED_CACHE_BYTES -- default min(25 % of MemAvailable when the package is imported, 16 GiB) -- in total; a result
+    that does not fit (after cached blocks of other sizes have been let go) is an ordinary pageable array, and so is any
+    result once the callers hold EKM_PINNED_LIVE_BYTES (default: the same number) alive (`ekm_hip.empty_cache()` frees
+    the cached blocks).  `ekm_hip.memory_stats()["pinned"]` reports both and what is in use.  An array in
+    pooled memory does not own its data: `.base` is a ctypes buffer and `ndarray.resize` refuses."""
+
+    @staticmethod
+    def machine_limit():
+        """min(25 % of MemAvailable, 16 GiB); 2 GiB when /proc/meminfo cannot be read."""
+        try:
+            with open("/proc/meminfo") as f:
+                for ln in f:
+                    if ln.startswith("MemAvailable:"):
+                        return int(min(int(ln.split()[1]) * 1024 // 4, 16 << 30))
+        except (OSError, ValueError, IndexError):
+            pass
+        return 2 << 30
 
     def __init__(self):
         self.free = {}    # bucket -> [ptr, ...]
         self.cached = 0
-        self.limit = int(os.environ.get("EKM_PINNED_CACHE_BYTES", str(2 << 30)))
-        self.live_limit = int(os.environ.get("EKM_PINNED_LIVE_BYTES", str(4 << 30)))  # pinned bytes callers may hold at once
+        env = os.environ.get("EKM_PINNED_CACHE_BYTES")
+        self.limit = int(env) if env else self.machine_limit()
+        env = os.environ.get("EKM_PINNED_LIVE_BYTES")
+        self.live_limit = int(env) if env else self.limit  # pinned bytes callers may hold at once (<= the limit anyway)
         # re-entrant: give() runs from a weakref finalizer, which the cyclic garbage collector may fire at any allocation
         # inside take() / give() / drain() of the very thread that holds the lock
         self.lock = threading.RLock()
@@ -523,18 +544,51 @@ class _PinnedPool:
         step = 1 << 20
         return max(step, (int(nbytes) + step - 1) // step * step)
 
+    def _evict_locked(self, need, keep=None):
+        """Let go of cached blocks, sizes unused the longest first (never size `keep`), until `need` more bytes fit under the
+        limit; returns the pointers to free (outside the lock)."""
+        out = []
+        while self.handed_out + self.cached + need > self.limit:
+            # (a snapshot: a finalizer fired by the garbage collector can re-enter give() right here)
+            sizes = [k for k, lst in list(self.free.items()) if lst and k != keep]
+            if not sizes:
+                break
+            old = min(sizes, key=lambda k: self.used.get(k, 0))
+            lst = self.free.get(old)
+            if not lst:
+                continue
+            out.append(lst.pop())
+            self.cached -= old
+        return out
+
     def take(self, nbytes):
+        """A pinned block of at least `nbytes` (pointer, bucket size), or (None, size) when the bounds say no: the caller
+        then uses an ordinary pageable array.  Invariant: blocks handed out + blocks cached <= `limit` bytes, ONE number
+        for all the page-locked memory of the pool; cached blocks of other sizes make room for a new one (a workload that
+        changes its field size is not stuck with a cache full of the old size)."""
         b = self.bucket(nbytes)
+        evicted = []
         with self.lock:
             if self.handed_out + b > self.live_limit:
                 return None, b  # the caller keeps many results alive: further ones are ordinary pageable arrays
-            self.handed_out += b  # reserved under the lock, before the (slow) allocation: the limit cannot be overshot
             self.tick += 1
             self.used[b] = self.tick
             lst = self.free.get(b)
             if lst:
                 self.cached -= b
+                self.handed_out += b
                 return lst.pop(), b
+            evicted = self._evict_locked(b, keep=None)
+            fits = self.handed_out + self.cached + b <= self.limit
+            if fits:
+                self.handed_out += b  # reserved under the lock, before the (slow) allocation: the limit cannot be overshot
+        try:
+            for p in evicted:
+                _ffi.lib().ekm_host_free(p)
+        except Exception:  # interpreter shutdown
+            pass
+        if not fits:
+            return None, b
         out = C.c_void_p()
         if _ffi.lib().ekm_host_alloc(b, C.byref(out)) < 0 or not out.value:
             with self.lock:
@@ -543,35 +597,20 @@ class _PinnedPool:
         return out.value, b
 
     def give(self, ptr, b):
-        """A block comes back.  It is cached if the limit allows -- making room, if need be, by letting go of blocks of the
-        sizes that have gone unused the longest (a workload that changes its field size must not be stuck with a cache full
-        of the old size, pinning its new blocks anew at every call)."""
-        evicted = []
+        """A block comes back: it moves from the callers' share to the cache (the total does not change)."""
         with self.lock:
             self.handed_out -= b
             self.tick += 1
             self.used[b] = self.tick
-            if b <= self.limit:
-                while self.cached + b > self.limit:
-                    # (a snapshot: a finalizer fired by the garbage collector can re-enter give() right here)
-                    sizes = [k for k, lst in list(self.free.items()) if lst and k != b]
-                    if not sizes:
-                        break
-                    old = min(sizes, key=lambda k: self.used.get(k, 0))
-                    lst = self.free.get(old)
-                    if not lst:
-                        continue
-                    evicted.append(lst.pop())
-                    self.cached -= old
-                if self.cached + b <= self.limit:
-                    self.free.setdefault(b, []).append(ptr)
-                    self.cached += b
-                    ptr = None
-        try:
-            for p in evicted + ([ptr] if ptr else []):
-                _ffi.lib().ekm_host_free(p)
-        except Exception:  # interpreter shutdown
-            pass
+            if self.handed_out + self.cached + b <= self.limit:
+                self.free.setdefault(b, []).append(ptr)
+                self.cached += b
+                ptr = None
+        if ptr:  # (only when the limit was lowered meanwhile)
+            try:
+                _ffi.lib().ekm_host_free(ptr)
+            except Exception:  # interpreter shutdown
+                pass
 
     def drain(self):
         with self.lock:

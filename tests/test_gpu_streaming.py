@@ -221,7 +221,7 @@ def test_lane_streams_are_bounded_and_releasable(ek):
     t, q, p = _fields(24, 1 << 18)
     for rows in (24, 17, 9):  # different leading-axis lengths must not create new streams per length
         _streamed._run_streamed("potential_temperature", (t[:rows], p[:rows]), (), None, None, [ek.current_device()])
-    assert 0 < len(_streamed._streams) <= _streamed._MAX_LANES
+    assert 0 < len(_streamed._streams) <= _streamed._MAX_LANES + 1  # the lanes and the one download stream
     ek.release_streams()
     assert len(_streamed._streams) == 0
     out = ek.thermo.potential_temperature(t, p)  # still works afterwards (streams are re-created on demand)

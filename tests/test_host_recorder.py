@@ -206,27 +206,44 @@ def test_a_device_resident_call_is_planned_once_and_launched_from_the_recipe(rec
 
 
 def test_pinned_pool_lets_go_of_the_sizes_that_went_unused_longest(rec, monkeypatch):
-    """device._PinnedPool: a cache full of one block size must not keep a workload with a new field size from caching its
-    blocks (every call would pin them anew): the oldest-unused sizes are evicted to make room, within the byte limit."""
+    """device._PinnedPool: ONE bound for all its page-locked memory (blocks handed out + blocks cached <= limit).  A cache
+    full of one block size must not keep a workload with a new field size from getting pinned blocks: the oldest-unused
+    sizes are let go to make room; what does not fit is refused (the caller takes a pageable array)."""
     pool = device._PinnedPool()
-    pool.limit, pool.live_limit = 8 << 20, 64 << 20
+    pool.limit, pool.live_limit = 8 << 20, 8 << 20
     rec.calls.clear()
     small = [pool.take(2 << 20) for _ in range(4)]              # four 2-MiB blocks: allocated
     assert [c[0] for c in rec.calls] == ["ekm_host_alloc"] * 4
+    assert pool.take(2 << 20)[0] is None                        # a fifth does not fit the bound: refused, nothing pinned
     for ptr, b in small:
         pool.give(ptr, b)
-    assert pool.cached == 8 << 20 and pool.handed_out == 0      # all four cached: the cache is full
+    assert pool.cached == 8 << 20 and pool.handed_out == 0      # all four cached: the pool is full
     rec.calls.clear()
-    big, bb = pool.take(6 << 20)                                # a new size: allocated ...
-    pool.give(big, bb)                                          # ... and cached, three of the old blocks let go
-    assert [c[0] for c in rec.calls] == ["ekm_host_alloc", "ekm_host_free", "ekm_host_free", "ekm_host_free"]
-    assert pool.cached == (6 << 20) + (2 << 20)
+    big, bb = pool.take(6 << 20)                                # a new size: three of the old blocks let go, then allocated
+    assert [c[0] for c in rec.calls] == ["ekm_host_free", "ekm_host_free", "ekm_host_free", "ekm_host_alloc"]
+    assert pool.handed_out + pool.cached == 8 << 20
+    pool.give(big, bb)
+    assert pool.cached == (6 << 20) + (2 << 20) and pool.handed_out == 0
     rec.calls.clear()
     again, _ = pool.take(6 << 20)                               # recycled: no allocation
     assert again == big and rec.calls == []
     pool.give(again, bb)
-    huge, hb = pool.take(16 << 20)                              # larger than the whole cache: never cached
-    pool.give(huge, hb)
-    assert pool.cached == 8 << 20 and rec.calls[-1][0] == "ekm_host_free"
+    huge, hb = pool.take(16 << 20)                              # larger than the whole bound: never pinned
+    assert huge is None and pool.handed_out == 0
+    pool.live_limit = 4 << 20                                   # callers may hold less than the pool may cache
+    assert pool.take(6 << 20)[0] is None and pool.take(2 << 20)[0] is not None
     pool.drain()
     assert pool.cached == 0
+
+
+def test_pinned_pool_bound_comes_from_the_machine(monkeypatch):
+    """min(25 % of MemAvailable, 16 GiB) unless EKM_PINNED_CACHE_BYTES says otherwise; memory_stats() reports it."""
+    monkeypatch.delenv("EKM_PINNED_CACHE_BYTES", raising=False)
+    monkeypatch.delenv("EKM_PINNED_LIVE_BYTES", raising=False)
+    pool = device._PinnedPool()
+    assert 0 < pool.limit <= 16 << 30 and pool.live_limit == pool.limit
+    with open("/proc/meminfo") as f:
+        avail = next(int(ln.split()[1]) * 1024 for ln in f if ln.startswith("MemAvailable:"))
+    assert pool.limit <= avail // 4 + (1 << 30)
+    monkeypatch.setenv("EKM_PINNED_CACHE_BYTES", str(3 << 20))
+    assert device._PinnedPool().limit == 3 << 20
