@@ -151,12 +151,11 @@ EKM_HD float m_pow(float x, float y) { return std::pow(x, y); }
 // fp64 on gfx950: there is no fp64 transcendental unit and the device libm pays for correctly rounded
 // results (pow alone is ~200 instructions).  Measured issue cost (tools/microbench/valu_rates_f64.hip):
 // v_fma_f64 5.2 clk per wave, v_rcp_f64 17 clk.  The parity bar for fp64 is 1e-6 relative, so by default
-// the three primitives are built to ~2e-9 (the GPU tests assert <= 1e-7 against the reference's fp64 goldens, one order
-// inside the bar; raw v_rcp_f64 is 4.6e-8 -- tools/microbench/f64_seed_accuracy.hip -- and its error would be multiplied
-// by exponents of up to 40 in es, so the reciprocal keeps its Newton step):
+// the three primitives are built to ~1e-10 (four orders inside the bar; the GPU tests assert <= 1e-9 against the
+// reference's fp64 goldens):
 //   rcp  = v_rcp_f64 seed + ONE Newton step (<= 1e-14);
-//   exp2 = round-to-nearest split + degree-6 minimax polynomial of 2^f, ln 2 folded in + v_ldexp_f64 (1.9e-9);
-//   log2 = v_frexp + 2*atanh(s), s = (m-1)/(m+1), as s*q(s^2) with a degree-3 minimax q (6.9e-10);
+//   exp2 = round-to-nearest split + degree-7 near-minimax polynomial of 2^f, ln 2 folded in + v_ldexp_f64 (4.0e-11);
+//   log2 = v_frexp + 2*atanh(s), s = (m-1)/(m+1), as s*q(s^2) with a degree-4 near-minimax q (4.2e-12);
 //   pow  = exp2(y*log2(x)).
 // -DEKM_F64_EXACT selects the <= 3e-16 versions (two Newton steps, degree-12 Taylor, atanh series to s^21)
 // for A/B comparison.  inf / 0 / NaN behave as in libm in both.
@@ -222,10 +221,13 @@ EKM_HD double m_log2(double x) {
 // each one with two v_mov_b32 in front of a v_fmac_f64 (122 v_mov per point in the six-output pipeline, ~10 % of its
 // issue time; profiles/r03).  Read through the scalar cache they are SGPR pairs, loaded once per wave, that
 // v_fma_f64 takes directly as its addend.  (static: one copy per translation unit / device module.)
-// Round 5: one degree less in each polynomial (exp2 degree 6: 1.9e-9, atanh degree 3: 6.9e-10; round 4: degree 7 / 4,
-// 4.0e-11 / 4.2e-12).  The bar is 1e-6; with these the six outputs of the pipeline stay below 1e-8 of the reference
-// (asserted <= 1e-7).  -DEKM_F64_R4_POLY keeps round 4's.
-#if defined(EKM_F64_R4_POLY)
+// Round 5 measured one degree less in each polynomial (-DEKM_F64_R5_POLY: exp2 degree 6, 1.9e-9; atanh degree 3, 6.9e-10):
+// the six-output pipeline 14.5 -> 14.2 ms, the Newton wet-bulb 10.2 -> 10.0 -- and row 470 of the reference's own 480-row
+// table beyond the bar (bolton35's one Newton step, whose dlnf cancels to 1e-5 of its terms there, amplifies a primitive's
+// error a thousandfold: 1.8e-6 against 1e-6).  Two per cent are not worth a miss on the reference's own test data: the
+// default keeps round 4's degree 7 / 4 (4.0e-11 / 4.2e-12).  Nor can the reciprocal drop its Newton step: raw v_rcp_f64 is
+// 4.6e-8 (tools/microbench/f64_seed_accuracy.hip) and feeds exponents of up to 40 in es.
+#if !defined(EKM_F64_R5_POLY)
 static __constant__ double kF64Coef[16] = {
     // 2^f on |f| <= 0.5, degree 7, near-minimax in relative error (4.0e-11), ln 2 folded in; ascending
     0.9999999999616818, 0.693147180728452, 0.24022651198156714, 0.05550410353429554, 0.009618027253757476,
@@ -247,7 +249,7 @@ static __constant__ double kF64Coef[16] = {
 #endif
 #define EKM_F64C(i) (kF64Coef[i])
 EKM_HD double exp2_poly(double f) {  // 2^f, |f| <= 0.5
-#if defined(EKM_F64_R4_POLY)
+#if !defined(EKM_F64_R5_POLY)
   double p = EKM_F64C(7);
   p = __builtin_fma(p, f, EKM_F64C(6));
 #else
@@ -262,7 +264,7 @@ EKM_HD double exp2_poly(double f) {  // 2^f, |f| <= 0.5
   return p;
 }
 EKM_HD double atanh_poly(double z) {  // atanh(s)/s, z = s^2
-#if defined(EKM_F64_R4_POLY)
+#if !defined(EKM_F64_R5_POLY)
   double p = EKM_F64C(12);
   p = __builtin_fma(p, z, EKM_F64C(11));
 #else

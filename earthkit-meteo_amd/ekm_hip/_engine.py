@@ -215,10 +215,65 @@ def run(name, args, ints=(), eps=None, dtype=None):
         recipe = _recipes.get(_recipe_key(name, args, ints))  # every operand a DeviceArray and the call seen before
         if recipe is not None and not _sharding():
             return _run_remembered(recipe, args, eps)
+        if recipe is None:
+            swapped = _scalars_on_device(args)
+            if swapped is not None:
+                args = swapped
+                recipe = _recipes.get(_recipe_key(name, args, ints))
+                if recipe is not None and not _sharding():
+                    return _run_remembered(recipe, args, eps)
     args, foreign = _adopt_foreign(args)
     if foreign is not None:
         return _hand_back(_run(name, args, ints, eps, dtype), foreign)
     return _run(name, args, ints, eps, dtype)
+
+
+# ---- Python scalars beside DeviceArrays ---------------------------------------------------------------------------------
+# `potential_temperature(t_dev, 85000.0)`: the scalar used to reach the kernel through the general path at every call (a
+# block, an asynchronous fill of its bit pattern, the whole plan: 37 us against 11 for the same call on two DeviceArrays).
+# Its value on the device is remembered instead -- one 0-d DeviceArray per (device, dtype, bit pattern), filled once -- and
+# the call is then a call on DeviceArrays, which has a recipe.  Only where that changes nothing: every array operand a
+# DeviceArray of ONE dtype on ONE device (a Python scalar is weak: the arrays' dtype wins, as in the reference), not while
+# recording (there the fill is a node of the graph and the value a constant of it), not inside multi_gpu().
+_scalar_cache = {}
+_SCALARS_MAX = 256
+
+
+def _scalars_on_device(args):
+    dt = dev = None
+    has_scalar = False
+    for a in args:
+        if type(a) is DeviceArray:
+            if dt is None:
+                dt, dev = a.dtype, a.device
+            elif a.dtype != dt or a.device != dev:
+                return None
+        elif type(a) in (float, int):
+            has_scalar = True
+        else:
+            return None
+    if not has_scalar or dt is None or _capturing() is not None or _sharding():
+        return None
+    out = []
+    for a in args:
+        if type(a) is DeviceArray:
+            out.append(a)
+            continue
+        bits = np.asarray(a, dtype=dt).tobytes()
+        key = (dev, dt.char, bits)
+        d = _scalar_cache.get(key)
+        if d is None:
+            if len(_scalar_cache) >= _SCALARS_MAX:
+                _scalar_cache.clear()
+            d = DeviceArray.empty((), dt, dev)
+            stream = current_stream()
+            words = np.frombuffer(bits, dtype=np.uint32)
+            base = d.on(stream)
+            for w in range(words.size):
+                _ffi.check(_ffi.lib().ekm_fill_u32(dev, base + 4 * w, int(words[w]), 1, stream))
+            _scalar_cache[key] = d
+        out.append(d)
+    return tuple(out)
 
 
 # ---- the device-resident call, remembered ---------------------------------------------------------------------------
@@ -267,10 +322,139 @@ def _run_remembered(rec, args, eps):
     return tuple(results)
 
 
+# ---- tiny NumPy calls -------------------------------------------------------------------------------------------------
+# `potential_temperature(np.array([264.12, 261.45]), np.array([85000., 85000.]))` -- the reference's quick start, and the
+# shape of its whole test suite: a few elements in, a few out.  The general path costs such a call two uploads, a launch,
+# a download and a wait plus a device block per array (100 us).  Here the operands are written into ONE pinned
+# host block per thread and device, the kernel reads them and writes its results THERE (pinned host memory is mapped into
+# the device's address space: for a few KiB the link's latency is nothing beside two copies), and the call is a launch and
+# a wait.  What the plan of such a call depends on -- entry point, enum arguments, each operand's shape and dtype -- is
+# remembered like a device-resident call's.
+_TINY_BYTES = 64 << 10     # inputs + outputs in the compute dtype
+_tiny_recipes = {}
+_tiny_tls = threading.local()
+
+
+class _TinyRecipe:
+    __slots__ = ("fn", "cdtype", "out_dtype", "shape", "n", "classes", "sizes", "offsets", "out_offsets", "nout", "has_eps",
+                 "ints", "all_scalar", "nbytes")
+
+
+def _tiny_key(name, args, ints):
+    parts = []
+    for a in args:
+        ta = type(a)
+        if ta is np.ndarray:
+            if a.size > _TINY_BYTES // 4:
+                return None
+            parts.append((a.shape, a.dtype.str))
+        elif ta is float or ta is int:
+            parts.append(ta)
+        elif isinstance(a, np.generic):
+            parts.append(((), a.dtype.str))
+        else:
+            return None  # lists, DeviceArrays, another library's arrays, HybridPressure: the general path
+    try:
+        return (name, tuple(ints)) + tuple(parts)
+    except TypeError:
+        return None
+
+
+def _tiny_plan(name, args, ints):
+    ins, outs, int_names, has_eps = OPS[name]
+    plan = _Plan(args, None)
+    if plan.on_device or plan.hybrid or plan.n == 0:
+        return None
+    item = plan.dtype.itemsize
+    classes, sizes, offsets, off = [], [], [], 0
+    for h in plan.host:
+        cls = classify(h.shape, plan.shape) if plan.n else (_ffi.FIELD, 0, 0)
+        if cls is None:
+            return None  # a broadcast pattern the general path materialises
+        classes.append(cls)
+        sizes.append(int(h.size))
+        offsets.append(off)
+        off += (h.size * item + 255) & ~255
+    out_offsets = []
+    for _ in outs:
+        out_offsets.append(off)
+        off += (plan.n * item + 255) & ~255
+    if off > _TINY_BYTES:
+        return None
+    rec = _TinyRecipe()
+    rec.fn = getattr(_ffi.lib(), f"ekm_{name}_{'f32' if plan.dtype == _F32 else 'f64'}")
+    rec.cdtype, rec.out_dtype, rec.shape, rec.n = plan.dtype, plan.out_dtype, plan.shape, plan.n
+    rec.classes, rec.sizes, rec.offsets, rec.out_offsets = classes, sizes, offsets, out_offsets
+    rec.nout, rec.has_eps, rec.ints, rec.all_scalar, rec.nbytes = len(outs), has_eps, [int(v) for v in ints], plan.all_scalar, off
+    return rec
+
+
+class _TinyBlock:
+    """64 KiB of pinned host memory, owned by one thread's state for one device; freed with it."""
+
+    def __init__(self):
+        ptr = C.c_void_p()
+        _ffi.check(_ffi.lib().ekm_host_alloc(_TINY_BYTES, C.byref(ptr)))
+        self.ptr = ptr.value
+        self.buf = (C.c_char * _TINY_BYTES).from_address(self.ptr)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.buf = None
+                _ffi.lib().ekm_host_free(self.ptr)
+                self.ptr = None
+        except Exception:  # interpreter shutdown
+            pass
+
+
+def _tiny_block(dev):
+    blocks = getattr(_tiny_tls, "blocks", None)
+    if blocks is None:
+        blocks = _tiny_tls.blocks = {}
+    b = blocks.get(dev)
+    if b is None:
+        b = blocks[dev] = _TinyBlock()
+    return b
+
+
+def _run_tiny(rec, args, eps):
+    dev, stream = current_device(), current_stream()
+    blk = _tiny_block(dev)
+    base, buf = blk.ptr, blk.buf
+    cargs = [dev, stream]
+    for a, cls, size, off in zip(args, rec.classes, rec.sizes, rec.offsets):
+        np.frombuffer(buf, dtype=rec.cdtype, count=size, offset=off)[...] = np.reshape(a, -1) if type(a) is np.ndarray else a
+        cargs.append(C.byref(_ffi.Operand(base + off, cls[0], 0, cls[1], cls[2])))
+    cargs += rec.ints
+    if rec.has_eps:
+        cargs.append(float(eps))
+    cargs += [base + off for off in rec.out_offsets]
+    cargs.append(rec.n)
+    lib = _ffi.lib()
+    _ffi.check(rec.fn(*cargs))
+    _ffi.check(lib.ekm_stream_sync(dev, stream))
+    out = []
+    for off in rec.out_offsets:
+        h = np.frombuffer(buf, dtype=rec.cdtype, count=rec.n, offset=off).reshape(rec.shape).astype(rec.out_dtype)  # a copy: fresh arrays
+        out.append(h[()] if rec.all_scalar else h)
+    return tuple(out)
+
+
 def _run(name, args, ints, eps, dtype):
     from .device import current_devices
 
     devs = current_devices()
+    if dtype is None and _capturing() is None and not (devs and len(devs) > 1):
+        key = _tiny_key(name, args, ints)
+        if key is not None:
+            rec = _tiny_recipes.get(key)
+            if rec is None and key not in _tiny_recipes:
+                if len(_tiny_recipes) >= _RECIPES_MAX:
+                    _tiny_recipes.clear()
+                rec = _tiny_recipes[key] = _tiny_plan(name, args, ints)  # None: not a tiny call (remembered as such)
+            if rec is not None:
+                return _run_tiny(rec, args, eps)
     numpy_only = not any(isinstance(a, (DeviceArray, HybridPressure)) for a in args)
     if devs and len(devs) > 1 and not numpy_only:
         # a DeviceArray lives on ONE GPU: computing on it inside multi_gpu() would silently use that single device
@@ -298,13 +482,13 @@ def _run(name, args, ints, eps, dtype):
 # staged through a ring of pinned buffers (44-57 GB/s in the pipeline), the caller's memory pinned in place slice by slice
 # (31-44), both together (43-54) -- and removed in round 4: none came near the default.
 # Pinned memory is page-locked: it cannot be swapped and counts against container and memlock limits.  So the pool is
-# bounded -- at most EKM_PINNED_CACHE_BYTES (2 GiB) of dropped result blocks stay cached, callers may hold at most
-# EKM_PINNED_LIVE_BYTES (4 GiB) of such results alive at once, and a call's results go there only if the pool would keep
-# them afterwards (EKM_PINNED_RESULTS_BYTES, default = the cache limit): blocks the pool cannot keep are pinned anew by
-# every call, and pinning is slow -- with a 1-GiB cache the 2.5 GB of results of a 32-level P3 call took 401 ms per call
-# from the pool against 82 ms as ordinary arrays (profiles/r04_host_path_rate.txt).  Beyond the limits results are
-# ordinary arrays, prefaulted from a helper thread.  A result in pooled memory does not own its data (`.base` is a ctypes
-# buffer; `ndarray.resize` refuses): EKM_PINNED_RESULTS=0 turns the pool off.
+# bounded -- blocks held by callers plus blocks cached never exceed EKM_PINNED_CACHE_BYTES in total (default min(25 % of
+# MemAvailable, 16 GiB): device._PinnedPool) --, and a call's results go there only if the pool would keep them
+# afterwards (EKM_PINNED_RESULTS_BYTES, default = that limit): blocks the pool cannot keep are pinned anew by every call,
+# and pinning is slow -- with a 1-GiB cache the 2.5 GB of results of a 32-level P3 call took 401 ms per call from the pool
+# against 82 ms as ordinary arrays (profiles/r04_host_path_rate.txt).  Beyond the limit results are ordinary arrays,
+# prefaulted from a helper thread.  A result in pooled memory does not own its data (`.base` is a ctypes buffer;
+# `ndarray.resize` refuses): EKM_PINNED_RESULTS=0 turns the pool off.
 _PINNED_OUT = os.environ.get("EKM_PINNED_RESULTS", "1") != "0"
 # a call's results go to the pinned pool only if the pool would KEEP them afterwards: the per-call limit is the cache limit
 from .device import _pinned as _pinned_pool  # noqa: E402

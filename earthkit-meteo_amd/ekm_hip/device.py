@@ -242,6 +242,9 @@ def _owners_snapshot():
 
 def empty_cache():
     """Return every cached device block to HIP (like torch.cuda.empty_cache), and the cached pinned host blocks."""
+    from . import _engine  # (imports this module: late)
+
+    _engine._scalar_cache.clear()  # the remembered Python scalars (0-d device arrays) go first: their blocks join the cache
     _cache.drain()
     _pinned.drain()
 

@@ -39,7 +39,7 @@ STEP_FACTOR = 16.0          # how many roundings of that size may add up (the sa
 KAPPA_FACTOR = 16.0         # measured on the host twin: <= 9.1
 MAX_STEP = 10.0             # ... and its Newton step a correction of the guess (benchmark distribution: <= 5.0 K)
 F64_ASSERT = 1e-7           # fp64 bar 1e-6; asserted one order inside it
-UNIT = {"f32": 2.0 ** -24, "f64": 2e-9}  # rounding unit of the arithmetic under test (fp64: the primitives' accuracy)
+UNIT = {"f32": 2.0 ** -24, "f64": 2e-10}  # rounding unit of the arithmetic under test (fp64: the primitives' accuracy)
 
 METHODS = ("ifs", "bolton35", "bolton39")
 T_METHODS = ("bisect", "newton")

@@ -84,13 +84,13 @@ def test_broadcast_modes(ek, tag):
 def test_scalar_list_and_readme(ek):
     g = golden()
     T = ek.thermo
-    # fp64: bar 1e-6 (north_star); the default fp64 primitives are built to ~2e-9 (exp2 1.9e-9), asserted <= 1e-7
+    # fp64: bar 1e-6 (north_star); the default fp64 primitives are built to ~1e-10 (exp2 4e-11), asserted <= 1e-9
     th = T.potential_temperature(264.12, 85000.0)
-    assert isinstance(th, np.float64) and np.isclose(th, g["scalar.theta"], rtol=1e-7)
-    assert np.isclose(T.saturation_vapour_pressure(np.float64(300.0)), g["scalar.es"], rtol=1e-7)
-    assert np.allclose(T.potential_temperature([264.12, 261.45], [85000, 85000]), g["list.theta"], rtol=1e-7)
+    assert isinstance(th, np.float64) and np.isclose(th, g["scalar.theta"], rtol=1e-9)
+    assert np.isclose(T.saturation_vapour_pressure(np.float64(300.0)), g["scalar.es"], rtol=1e-9)
+    assert np.allclose(T.potential_temperature([264.12, 261.45], [85000, 85000]), g["list.theta"], rtol=1e-9)
     out = T.potential_temperature(np.array([264.12, 261.45]), np.array([85000.0, 85000.0]))
-    assert out.dtype == np.float64 and np.allclose(out, g["readme.theta"], rtol=1e-7)
+    assert out.dtype == np.float64 and np.allclose(out, g["readme.theta"], rtol=1e-9)
     assert T.potential_temperature(np.array([280, 281]), np.array([90000, 80000])).dtype == np.float64  # ints -> fp64
 
 
@@ -270,7 +270,7 @@ def test_fused_pipelines(ek, orc, slab, tag):
     for name, a in (("es", es), ("td", td), ("rh", rh), ("es", es5), ("td", td5), ("rh", rh5), ("th", th),
                     ("the", the), ("tw", tw)):
         # same formulas inlined into a different kernel: FMA contraction may differ by rounding only
-        assert_parity(a, sep[name], tag, f"fused {name} vs the separate kernel", rtol=1e-5 if tag == "f32" else 1e-7,
+        assert_parity(a, sep[name], tag, f"fused {name} vs the separate kernel", rtol=1e-5 if tag == "f32" else 1e-9,
                       unstable=newton_regime_boundary("pipeline_full", [t, q, p], {}, 1e-5) if name == "tw" else None)
     edge = newton_regime_boundary("pipeline_full", [t, q, p], {}, 1e-5 if tag == "f32" else 1e-13)
     for k, (got, want) in enumerate(zip((th, es5, rh5, td5, the, tw), orc.pipeline_full(t.copy(), q.copy(), p.copy()))):
@@ -706,7 +706,7 @@ def test_input_layouts_the_reference_accepts(ek, orc):
             assert np.array_equal(np.asarray(x), k), f"{name}: input mutated"
     ti = np.arange(250, 300, 5)  # integers -> fp64
     got = T.potential_temperature(ti, np.full(ti.shape, 90000))
-    assert got.dtype == np.float64 and np.allclose(got, O.potential_temperature(ti, np.full(ti.shape, 90000)), rtol=1e-7)
+    assert got.dtype == np.float64 and np.allclose(got, O.potential_temperature(ti, np.full(ti.shape, 90000)), rtol=1e-9)
     for shape in ((0,), (0, 5), (3, 0, 2)):
         e = np.empty(shape, np.float32)
         out = T.potential_temperature(e, e)

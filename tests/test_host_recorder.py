@@ -205,6 +205,93 @@ def test_a_device_resident_call_is_planned_once_and_launched_from_the_recipe(rec
         ekm_hip.thermo.potential_temperature(t, one)            # remembered, but sharding goes the general way (and refuses)
 
 
+def test_a_python_scalar_beside_device_arrays_is_uploaded_once(rec, monkeypatch):
+    """`potential_temperature(t_dev, 85000.0)`: the scalar's value is kept on the device (one 0-d array per device, dtype
+    and bit pattern) and the call becomes a remembered call on DeviceArrays -- the first call fills and plans, repeats
+    hand the library one launch each; another value is another fill; recording a graph does not use the memory (the fill
+    is a node of the graph there)."""
+    from ekm_hip import _engine
+
+    monkeypatch.setattr(_engine, "_recipes", {})
+    monkeypatch.setattr(_engine, "_scalar_cache", {})
+    t = ekm_hip.DeviceArray.empty((30, 64), np.float32)
+    rec.calls.clear()
+    a = ekm_hip.thermo.potential_temperature(t, 85000.0)
+    first = rec.names()
+    assert first.count("ekm_fill_u32") == 1 and first.count("ekm_potential_temperature_f32") == 1
+    assert isinstance(a, ekm_hip.DeviceArray) and a.dtype == np.float32 and a.shape == (30, 64)
+    rec.calls.clear()
+    rec.operands.clear()
+    for _ in range(3):
+        ekm_hip.thermo.potential_temperature(t, 85000.0)
+    assert [n for n in rec.names() if not n.startswith("ekm_malloc")] == ["ekm_potential_temperature_f32"] * 3   # no fill, no plan
+    launches = [o for o in rec.operands if o]
+    assert all(o == launches[0] for o in launches) and launches[0][1][1] == _ffi.SCALAR          # the same scalar block each time
+    rec.calls.clear()
+    ekm_hip.thermo.potential_temperature(t, 85000)              # an int of the same value: the same float32 bits
+    ekm_hip.thermo.potential_temperature(t, 90000.0)            # another value: one more fill
+    assert rec.names().count("ekm_fill_u32") == 1
+    t64 = ekm_hip.DeviceArray.empty((30, 64), np.float64)
+    rec.calls.clear()
+    b = ekm_hip.thermo.potential_temperature(t64, 85000.0)      # weak scalar: the arrays' dtype wins, two words filled
+    assert b.dtype == np.float64 and rec.names().count("ekm_fill_u32") == 2
+    before = dict(_engine._scalar_cache)
+    with ekm_hip.graph():
+        ekm_hip.thermo.potential_temperature(t, 77000.0)        # recorded: the fill belongs to the graph, nothing remembered
+    assert _engine._scalar_cache == before
+    ekm_hip.empty_cache()
+    assert _engine._scalar_cache == {}
+
+
+def test_a_tiny_numpy_call_is_a_launch_and_a_wait(rec, monkeypatch):
+    """The reference's quick start (README.md:39-58), two elements in, two out: operands written into one pinned block per
+    thread, which the kernel reads and writes in place -- no device block, no copy in either direction; planned once."""
+    from ekm_hip import _engine
+
+    class Block:  # (the recorder hands out numbers, not memory: a real buffer in place of the pinned block)
+        def __init__(self):
+            _ffi.lib().ekm_host_alloc(_engine._TINY_BYTES, C.byref(C.c_void_p()))
+            self.buf = C.create_string_buffer(_engine._TINY_BYTES)
+            self.ptr = C.addressof(self.buf)
+
+    monkeypatch.setattr(_engine, "_TinyBlock", Block)
+    monkeypatch.setattr(_engine, "_tiny_recipes", {})
+    monkeypatch.setattr(_engine, "_tiny_tls", type("T", (), {})())
+    planned = []
+    real = _engine._tiny_plan
+    monkeypatch.setattr(_engine, "_tiny_plan", lambda *a: planned.append(a[0]) or real(*a))
+    t, p = np.array([264.12, 261.45]), np.array([85000.0, 85000.0])
+    rec.calls.clear()
+    out = ekm_hip.thermo.potential_temperature(t, p)
+    assert isinstance(out, np.ndarray) and out.dtype == np.float64 and out.shape == (2,)
+    assert rec.names() == ["ekm_host_alloc", "ekm_potential_temperature_f64", "ekm_stream_sync"]
+    rec.calls.clear()
+    rec.operands.clear()
+    for _ in range(3):
+        again = ekm_hip.thermo.potential_temperature(t, p)
+    assert rec.names() == ["ekm_potential_temperature_f64", "ekm_stream_sync"] * 3 and planned == ["potential_temperature"]
+    assert again is not out and again.base is None                       # fresh arrays every time
+    ops = [o for o in rec.operands if o]
+    assert all(o == ops[0] for o in ops) and [m for _, m, _, _ in ops[0]] == [_ffi.FIELD, _ffi.FIELD]
+    blk = _engine._tiny_tls.blocks[0]
+    assert np.frombuffer(blk.buf, np.float64, 2, ops[0][0][0] - blk.ptr).tolist() == t.tolist()   # the operands sit in the block
+    # scalars in, a NumPy scalar out; float32 stays float32; float16 computes in float32 and comes back as float16
+    s = ekm_hip.thermo.potential_temperature(264.12, 85000.0)
+    assert isinstance(s, np.float64)
+    assert ekm_hip.thermo.potential_temperature(t.astype(np.float32), 85000.0).dtype == np.float32
+    assert ekm_hip.thermo.potential_temperature(t.astype(np.float16), (p * 0.5).astype(np.float16)).dtype == np.float16
+    # a level vector against a small field keeps its broadcast class; lists and big arrays go the general way
+    rec.calls.clear()
+    ekm_hip.thermo.potential_temperature(np.ones((4, 16)), np.linspace(5e4, 1e5, 4)[:, None])
+    assert rec.names()[-2:] == ["ekm_potential_temperature_f64", "ekm_stream_sync"] and rec.operands[-2][1][1] == _ffi.LEVEL_MAJOR
+    rec.calls.clear()
+    ekm_hip.thermo.potential_temperature([264.12, 261.45], [85000, 85000])
+    assert "ekm_h2d" in rec.names() and "ekm_d2h" in rec.names()
+    rec.calls.clear()
+    ekm_hip.thermo.potential_temperature(np.ones(1 << 16), np.ones(1 << 16))
+    assert "ekm_h2d" in rec.names()
+
+
 def test_pinned_pool_lets_go_of_the_sizes_that_went_unused_longest(rec, monkeypatch):
     """device._PinnedPool: ONE bound for all its page-locked memory (blocks handed out + blocks cached <= limit).  A cache
     full of one block size must not keep a workload with a new field size from getting pinned blocks: the oldest-unused
