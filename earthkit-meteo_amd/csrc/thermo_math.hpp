@@ -475,18 +475,31 @@ EKM_HD T es_ice(T t) {  // es_comp.py:137-138
   return m_exp2(m_fma((t - T(k::T0)) * m_rcp(t - T(k::C4I)), T(k::C3I * k::LOG2E), T(k::LOG2_C1)));
 }
 
-// es and d(es)/dT for one phase from one reciprocal (es_comp.py:169-174)
-template <class T>
+// es and d(es)/dT for one phase from one reciprocal (es_comp.py:169-174).
+// ONE_FMA (the IFS Newton step and its regime-1 guess only -- the VALU-bound kernels of BASELINE configs 4 and 5):
+// (t - T0)/(t - C4) = 1 - (T0 - C4)*r, so the exponent is ONE fma of r = 1/(t - C4) instead of a subtraction, a product and
+// an fma.  The cancellation costs the exponent 1.5e-6 absolute in fp32 -- es to 6e-6 of the reference instead of 2.5e-6
+// over 180-330 K, against a bar of 1e-4; nothing in fp64.  Everything else keeps the reference's operator order: the es
+// OUTPUTS, the slope functions, the bisection's tables (a wider error band would move rounding-level sign decisions) and
+// the Bolton Newton steps (whose cancelling dlnf amplifies an es error a thousandfold on unphysical input: with the
+// one-fma form there the wide-domain fuzz counted 5,500 points beyond 1e-4 where the reference's own fp32 run has 2,300).
+template <bool ONE_FMA = false, class T>
 EKM_HD void es_slope_water(T t, T& es, T& des) {
   const T r = m_rcp(t - T(k::C4W));
-  es = m_exp2(m_fma((t - T(k::T0)) * r, T(k::C3W * k::LOG2E), T(k::LOG2_C1)));
+  if (ONE_FMA)
+    es = m_exp2(m_fma(r, T(-k::C3W * k::LOG2E * (k::T0 - k::C4W)), T(k::C3W * k::LOG2E + k::LOG2_C1)));
+  else
+    es = m_exp2(m_fma((t - T(k::T0)) * r, T(k::C3W * k::LOG2E), T(k::LOG2_C1)));
   des = es * T(k::sw) * (r * r);
 }
 
-template <class T>
+template <bool ONE_FMA = false, class T>
 EKM_HD void es_slope_ice(T t, T& es, T& des) {
   const T r = m_rcp(t - T(k::C4I));
-  es = m_exp2(m_fma((t - T(k::T0)) * r, T(k::C3I * k::LOG2E), T(k::LOG2_C1)));
+  if (ONE_FMA)
+    es = m_exp2(m_fma(r, T(-k::C3I * k::LOG2E * (k::T0 - k::C4I)), T(k::C3I * k::LOG2E + k::LOG2_C1)));
+  else
+    es = m_exp2(m_fma((t - T(k::T0)) * r, T(k::C3I * k::LOG2E), T(k::LOG2_C1)));
   des = es * T(k::si) * (r * r);
 }
 
@@ -521,20 +534,20 @@ EKM_HD T es_mixed(T t) {
 }
 
 // es and slope of the mixed phase together (es_comp.py:177-200)
-template <class T>
+template <bool ONE_FMA = false, class T>
 EKM_HD void es_slope_mixed(T t, T& es, T& des) {
   const bool ice = t <= T(k::TI), wat = t >= T(k::T0);
   if (!EKM_ANY(!ice)) {
-    es_slope_ice(t, es, des);
+    es_slope_ice<ONE_FMA>(t, es, des);
     return;
   }
   if (!EKM_ANY(!wat)) {
-    es_slope_water(t, es, des);
+    es_slope_water<ONE_FMA>(t, es, des);
     return;
   }
   T ew, dw, ei, di;
-  es_slope_water(t, ew, dw);
-  es_slope_ice(t, ei, di);
+  es_slope_water<ONE_FMA>(t, ew, dw);
+  es_slope_ice<ONE_FMA>(t, ei, di);
   const T x = t - T(k::TI);
   const T a = m_sq(x * T(1.0 / (k::T0 - k::TI)));
   const T da = T(k::dalpha_c) * x;
@@ -1299,7 +1312,7 @@ EKM_HD T t_on_ma_bisect(T e, T p) {
 // c_te > D, 1 <= c_te <= D, 0.4 <= c_te < 1, c_te < 0.4 -- i.e. what the reference's fp32 sequence computes
 // up to its own rounding noise.  The guess FORMULAS stay in fp32 (they are continuous in c_te).
 struct Regime {
-  bool r1, r2, r3, r4;  // c_te > D | 1 <= c_te <= D | 0.4 <= c_te < 1 | c_te < 0.4  (all false for NaN)
+  bool r1, r2, r3, r4;  // c_te > D | 1 <= c_te <= D | 0.4 <= c_te < 1 | c_te < 0.4  (a NaN c_te: r2 alone, whose guess is NaN then)
 };
 
 constexpr double kTieBand = 4e-6;  // > 3x the worst fp32 error of the fast c_te (te ~3e-7, x lambda, + exp2/log2)
@@ -1405,11 +1418,16 @@ EKM_HD Regime davies_regime(T c_te, T cd, T p, const TeExact& te_exact, Tie& tie
   }
 #endif
   (void)tie;
+  // Three comparisons, the rest is mask logic on the scalar unit: r3 = c < 1 and not c < 0.4; r2 = not c < 1 and not
+  // c/D > 1.  For an ordered c_te these ARE the reference's masks (1 <= c_te <= D, 0.4 <= c_te < 1); a NaN c_te, for
+  // which the reference selects nothing, lands in r2 here -- and every guess formed from a NaN c_te is NaN, as is what
+  // the reference then carries through its Newton step (tw = ept with a NaN c_te in the residual).
   Regime r;
+  const bool lt1 = c_dec < T(1);
   r.r1 = cd_dec > T(1);
-  r.r2 = T(1) <= c_dec && cd_dec <= T(1);
-  r.r3 = T(0.4) <= c_dec && c_dec < T(1);
   r.r4 = c_dec < T(0.4);
+  r.r3 = lt1 && !r.r4;
+  r.r2 = !lt1 && !r.r1;
   return r;
 }
 
@@ -1457,7 +1475,7 @@ EKM_HD T t_on_ma_newton_ifs_core(T lte, T p, T dinv, const TeFn& te_fn, const Pp
   if (EKM_ANY(R.r1)) {
     const T te = te_fn();
     T es, des;
-    es_slope_mixed(te, es, des);
+    es_slope_mixed<true>(te, es, des);
     // te - t0 - A*ws/(1 + A*ws*des/es) with ws = eps*es/v, v = p - es (thermo.py:1116-1119): the two divisions are one,
     // A*eps*es/(v + A*eps*des).  v is NaN where p - es < eps, and where the reference's es underflows to zero its
     // des/es is 0/0 (es_zero_below; an es of ours that is zero above that temperature leaves te - t0, as it should).
@@ -1487,7 +1505,7 @@ EKM_HD T t_on_ma_newton_ifs_core(T lte, T p, T dinv, const TeFn& te_fn, const Pp
   // step's denominator -- instead of three.
   const T ltw = m_log2(tw * T(1.0 / 273.16));
   T es, des;
-  es_slope_mixed(tw, es, des);
+  es_slope_mixed<true>(tw, es, des);
   T v = m_fma(T(k::eps - 1), es, p);
   if ((p - es) < T(k::eps_default)) v = nan_v<T>();
   const T r2 = m_rcp(v * tw);

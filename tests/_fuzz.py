@@ -15,7 +15,8 @@ What is asserted, against the oracle run in the SAME dtype (the oracle is pinned
     decided from the oracle alone, never from the output under test; the bar of a point is the largest of
       - 4*delta, delta = the reference's own fp32-vs-fp64 distance;
       - 16 x unit x the first-order rounding bound of that line with every operand carrying roundings of its own size:
-        [|guess| + (|f| + |c_te|)/|f*dlnf| + |step|*((lambda/guess)/|dlnf| + guess*|d ln f/dT| + |ln f| + |ln c_te|)]/tw,
+        [|guess| + (|f| + |c_te|)/|f*dlnf| + |step|*(E*max(lambda/guess, |d ln f/dT|)/|dlnf| + guess*|d ln f/dT| + E*|ln f| + |ln c_te|)]/tw
+        (E = 100 in fp32: es = exp of an exponent of 20-40 carries that many rounding units, the reference's own included),
         operands from the fp64 oracle (thermo_oracle._t_on_ma_newton(return_parts=True)): 2-5 on the benchmark
         distribution (nothing relaxed), 1e3-1e6 where theta_e of 1000-3000 K or q of 0.1-0.9 makes the single step move
         the guess by 50-250 K and land at 0.05 K or 1e15 K, or where bolton35's dlnf cancels to 1e-5 against terms of 5e-3
@@ -35,6 +36,7 @@ from _compare import CENSUS, ILL_CONDITIONED_FRACTION, _record, assert_parity, b
 N_POINTS = 1 << 20
 SEED = 20261004
 PHYS = (150.0, 400.0)       # the reference's result is an atmospheric temperature ...
+ES_UNITS = {"f32": 100.0, "f64": 1.0}  # rounding units es carries (fp64: inside UNIT already)
 STEP_FACTOR = 16.0          # how many roundings of that size may add up (the same allowance as for kappa below)
 KAPPA_FACTOR = 16.0         # measured on the host twin: <= 9.1
 MAX_STEP = 10.0             # ... and its Newton step a correction of the guess (benchmark distribution: <= 5.0 K)
@@ -106,12 +108,16 @@ def judge(func, keys, method, t_method, tag, d, got):
         phys = (w64 >= PHYS[0]) & (w64 <= PHYS[1]) & (step <= MAX_STEP)
         # first-order rounding bound of the reference's own last line, tw = guess - (f - c_te)/(f*dlnf), every operand
         # carrying roundings of its own size: the subtraction of guess and step; f - c_te over f*dlnf; dlnf = -lambda*(1/tw
-        # + ...) a sum that may cancel (its first term alone is lambda/guess); f = exp(ln f) evaluated at a rounded guess
+        # + ...) a sum that may cancel (its terms are of the size of lambda/guess and of the true d ln f / d tw); f = exp(ln f) evaluated at a rounded guess
         # (d ln f / d tw by central difference on the oracle) through exponents of |ln f|, c_te likewise
         af, ac, ad, at = (np.abs(parts[k]).reshape(w64.shape) for k in ("f", "c_te", "dlnf", "dlnf_true"))
         at = np.where(np.isfinite(at), np.maximum(at, ad), ad)
+        # es (and with it ws, qs and their slopes) is exp of an exponent of 20-40: it carries ES_UNITS rounding units, in the
+        # reference's own fp32 evaluation (2.5e-6 = 40 units over 180-330 K) as in the kernels' (up to 6e-6 = 100 units in
+        # the Newton step's one-fma form, thermo_math.hpp::es_slope_water); ln f is linear in it, dlnf's terms too
+        eu = ES_UNITS[tag]
         cond = (np.abs(guess) + (af + ac) / (af * ad)
-                + step * ((orc.LAMBDA / np.abs(guess)) / ad + np.abs(guess) * at + np.abs(np.log(af)) + np.abs(np.log(ac)))) / np.abs(w64)
+                + step * (eu * np.maximum(orc.LAMBDA / np.abs(guess), at) / ad + np.abs(guess) * at + eu * np.abs(np.log(af)) + np.abs(np.log(ac)))) / np.abs(w64)
     bar = np.where(np.isfinite(cond), np.maximum(bar, STEP_FACTOR * cond * UNIT[tag]), bar)
     # beyond every bar: the reference's conditioning with respect to its inputs must explain it (kappa / NaN edges)
     miss = nanmm | (r > bar)
