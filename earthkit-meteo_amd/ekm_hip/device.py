@@ -293,6 +293,12 @@ class _Allocation:
             out = C.c_void_p()
             rc = _ffi.lib().ekm_malloc(device, self.bucket, C.byref(out))
             if rc < 0:  # out of memory: give the cached blocks back and retry once
+                if _capturing() is not None:
+                    # ... but not while recording: returning blocks to HIP synchronises the device, which a capturing
+                    # thread must not do -- the block says what to do instead
+                    raise _ffi.EkmError(f"out of device memory for a {self.bucket}-byte result inside an ekm_hip.graph() block (the "
+                                        "recording stream has no cached blocks of its own): call ekm_hip.empty_cache() before the "
+                                        "block, or run the block's calls once eagerly on a stream whose blocks you then free")
                 _cache.drain()
                 _ffi.check(_ffi.lib().ekm_malloc(device, self.bucket, C.byref(out)))
             ptr = out.value
