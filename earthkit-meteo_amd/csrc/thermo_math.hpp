@@ -824,7 +824,7 @@ EKM_HD void bisect_es_fill(double* __restrict__ tab, int m) { tab[m] = es_mixed(
 // The 12 halvings visit the nodes of a complete binary tree over the lattice: depth d holds the lattice points
 // m = (2j + 1) * 2^(11-d), j = 0 .. 2^d - 1, and the next node is the left or right child by the sign of the residual.
 // With the nodes stored in heap order (node i, children 2i and 2i + 1) the whole search state is ONE integer and a step
-// is i = i + i + (r > 0): one compare and one add-with-carry, no temperature arithmetic, no index conversion.
+// is i = i + i + (r > 0): ONE v_alignbit_b32 on the sign of -r (bisect_heap_child), no temperature arithmetic, no index conversion.
 //
 // The reference decides on r = theta_e*exp(G_sat) - th_sat (thermo.py:1075), i.e. after division by the positive
 // (p0/p)^kappa on  r_m = te*2^(g_m) - t_m,  g_m = a_m/w_m,  w_m = p + (eps - 1)*es_m  (one rcp and one exp2 per step;
@@ -837,7 +837,8 @@ EKM_HD void bisect_es_fill(double* __restrict__ tab, int m) { tab[m] = es_mixed(
 // with |D_m| <= kHeapTau0*p + kHeapTau1*|a_m| (four times those bounds, p >= w) is AMBIGUOUS and is decided by the
 // reference's own arithmetic, evaluated for the wave -- a wave-uniform branch, taken on about two of the twelve steps
 // of a wave (the last ones, where some lane of the wave stands within a millikelvin of its root).  So every decision is
-// the stepwise search takes, bit for bit, at ~10 plain instructions per step instead of 11 + 2 transcendentals.
+// the stepwise search takes, bit for bit, at 7 plain instructions per step (round 4: 10; the stepwise search: 11 + 2
+// transcendentals).
 // `all_exact` (tuning parameter bisect_exact) makes every step ambiguous: the stepwise search itself, against which
 // tests/test_gpu_census.py compares the default on every point of the benchmark field.
 //
@@ -845,7 +846,8 @@ EKM_HD void bisect_es_fill(double* __restrict__ tab, int m) { tab[m] = es_mixed(
 // ambiguous: the exact branch records the node's temperature (or the NaN) as the lane's final answer, together with the
 // largest es visited so far -- the reference keeps re-evaluating the same point from then on -- for the NaN rule
 // `p - max(es visited) < eps` (thermo.py:192-196, applied once at the end).
-// Table layout (48 KiB of LDS per workgroup): 4096 pairs (es_i, a_i) in heap order, then the 4096 L_i; node 0 unused.
+// Table layout: heap order, node 0 unused; 4096 (es_i, a_i) pairs then the 4096 L_i (48 KiB) or 4096 16-byte records (es_i,
+// a_i, t_i, L_i) read by one ds_read_b128 (64 KiB: the fp32 IFS walk) -- heap_rec / heap_read below.
 constexpr int kHeapNodes = kBisectLattice;
 constexpr double kHeapTau0 = 2.5e-6, kHeapTau1 = 1.2e-6;
 
