@@ -696,6 +696,14 @@ EKM_HD T ept(T t, T hum, T p) {
   return th * m_exp((m_div(T(3036.0), tl) - T(1.78)) * w * (T(1) + T(0.448) * w));
 }
 
+// exp2 whose result may be a denormal (v_exp_f32 flushes those to zero; the reference's exp / pow round them).  Needed
+// where the reference's own arithmetic meets such a value again: the exact step of the bolton35 search (its two terms
+// are compared where both are that small) and bolton35's th_sat (a denormal th_sat times an overflowed exp(G) is inf in
+// the reference, 0*inf = NaN only once th_sat has gone to zero altogether).
+EKM_HD float m_exp2_denorm(float x) { return x < -100.0f ? m_exp2(x + 64.0f) * 0x1p-64f : m_exp2(x); }
+EKM_HD double m_exp2_denorm(double x) { return m_exp2(x); }
+EKM_FD fd64<F> m_exp2_denorm(fd64<F> x) { return m_exp2(x); }
+
 // th_sat and G_sat(scale) of the saturated parcel (thermo.py:1177-1182,
 // 1215-1224, 1280-1295).  bolton39 masks es where p - es < 1e-4.
 template <int METHOD, class T>
@@ -707,7 +715,7 @@ EKM_HD void sat_terms(T t, T p, T scale, T& th_sat, T& g_sat) {
     g_sat = m_div((scale * T(k::K0_ifs)) * qs, t);
   } else if (METHOD == EPT_BOLTON35) {
     const T ws = w_from_e(es, p, T(k::eps_default));
-    th_sat = t * m_pow(m_div(T(k::p0), p), T(k::kappa) * (T(1) - T(0.28) * ws));
+    th_sat = t * m_exp2_denorm((T(k::kappa) * (T(1) - T(0.28) * ws)) * m_log2(m_div(T(k::p0), p)));
     g_sat = m_div((scale * T(2675.0)) * ws, t);
   } else {
     if ((p - es) < T(1e-4)) es = nan_v<T>();
@@ -968,11 +976,6 @@ EKM_HD unsigned bisect_heap_child(unsigned node, float nr) {
 // denominator the exact step divides by (ifs: p + (eps-1)*es; Bolton: p - es); thr0 = the part of the band that goes with p.
 constexpr double kB35WsExact = 2.0;
 
-// exp2 whose result may be a denormal (v_exp_f32 flushes those to zero; the reference's exp / pow round them): only the
-// exact step of the bolton35 search, whose two terms are compared where both are that small, needs it
-EKM_HD float m_exp2_denorm(float x) { return x < -100.0f ? m_exp2(x + 64.0f) * 0x1p-64f : m_exp2(x); }
-EKM_HD double m_exp2_denorm(double x) { return m_exp2(x); }
-EKM_FD fd64<F> m_exp2_denorm(fd64<F> x) { return m_exp2(x); }
 
 // The reference's bolton35 residual as it stands, theta_e*exp(G_sat(scale=-1)) - th_sat (thermo.py:1075, 1215-1224), in
 // base 2: theta_e*2^(a_m*ws) - t_m*2^(kl*(0.28*ws - 1)), a_m = -2675*log2(e)/t_m, kl = kappa*log2(p/p0).  NOT divided by

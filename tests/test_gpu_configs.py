@@ -179,3 +179,67 @@ def test_cfg5_full_pipeline_full_size(ek, field):
                               equal_nan=True)
     for o in outs + part:
         o.free()
+
+
+# ---- small calls: the two host paths give the same bits --------------------------------------------
+def test_tiny_numpy_calls_equal_the_general_path_bit_for_bit_and_are_thread_safe(ek, monkeypatch):
+    """A NumPy call whose operands and results fit 64 KiB runs on one pinned block per thread that the kernel reads and
+    writes in place (ekm_hip/_engine.py::_run_tiny); everything else is uploaded, computed, downloaded.  Same kernels, same
+    bits -- for field / scalar / level-vector operands, one to six outputs, fp32, fp64 and float16 in; and four threads
+    calling at once (each has its own block) get their own results."""
+    import threading
+
+    from ekm_hip import _engine
+
+    rng = np.random.default_rng(7)
+    t = rng.uniform(200.0, 320.0, (6, 80))
+    q = 10.0 ** rng.uniform(-6.0, -1.8, (6, 80))
+    p = np.linspace(2e4, 1.0e5, 6)[:, None] * np.ones((1, 80))
+    T = ek.thermo
+    cases = [
+        (T.potential_temperature, (t, p), {}),
+        (T.potential_temperature, (t, p[:, :1]), {}),                                    # a level vector
+        (T.potential_temperature, (t, 85000.0), {}),                                      # a Python scalar
+        (T.relative_humidity_from_specific_humidity, (t, q, p), {}),
+        (T.pipeline_full, (t, q, p), {}),
+        (T.wet_bulb_temperature_from_specific_humidity, (t, q, p), {}),                   # the tree walk: LDS table, 1024 threads
+        (T.wet_bulb_temperature_from_specific_humidity, (t, q, p), {"ept_method": "bolton39", "t_method": "newton"}),
+        (T.lcl, (t, t - 3.0, p), {}),
+        (T.specific_humidity_from_vapour_pressure, (q * 1e4, p), {"eps": 1e-3}),
+    ]
+    calls = []
+    real = _engine._run_tiny
+    monkeypatch.setattr(_engine, "_run_tiny", lambda *a: calls.append(1) or real(*a))
+    for dtype in (np.float64, np.float32, np.float16):
+        for fn, args, kw in cases:
+            a = [x.astype(dtype) if isinstance(x, np.ndarray) else x for x in args]
+            n0 = len(calls)
+            tiny = fn(*a, **kw)
+            assert len(calls) == n0 + 1, (fn.__name__, dtype)                             # it did take the tiny path
+            monkeypatch.setattr(_engine, "_TINY_BYTES", 0)
+            monkeypatch.setattr(_engine, "_tiny_recipes", {})
+            general = fn(*a, **kw)
+            monkeypatch.undo()
+            monkeypatch.setattr(_engine, "_run_tiny", lambda *a: calls.append(1) or real(*a))
+            for x, y in zip(tiny if isinstance(tiny, tuple) else (tiny,), general if isinstance(general, tuple) else (general,)):
+                assert x.dtype == y.dtype == dtype and x.shape == y.shape
+                assert np.array_equal(x, y, equal_nan=True), (fn.__name__, dtype)
+    want = {k: T.potential_temperature(t[k % 6], p[k % 6]) for k in range(4)}
+    got, errs = {}, []
+
+    def work(k):
+        try:
+            for _ in range(200):
+                r = T.potential_temperature(t[k % 6], p[k % 6])
+                if not np.array_equal(r, want[k]):
+                    errs.append(k)
+            got[k] = r
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs and len(got) == 4, errs

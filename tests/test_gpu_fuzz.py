@@ -39,6 +39,15 @@ def test_fuzz_against_the_oracle(ek, points, dev_points, func, keys, method, t_m
     print(_fuzz.judge(func, keys, method, t_method, tag, d, got))
 
 
+@pytest.mark.parametrize("func,keys,kwargs", _fuzz.DIRECT, ids=[f"{f}-{'-'.join(map(str, kw.values()))}" for f, _, kw in _fuzz.DIRECT])
+def test_direct_functions_on_the_fuzz_domain(ek, points, dev_points, func, keys, kwargs):
+    tag, dtype, d = points
+    out = getattr(ek.thermo, func)(*[dev_points[k] for k in keys], **kwargs)
+    got = out.to_host()
+    out.free()
+    print(_fuzz.judge_direct(func, keys, kwargs, tag, d, got))
+
+
 def _exact(on):
     from ekm_hip import _ffi
 

@@ -30,6 +30,13 @@ def test_fuzz_against_the_oracle(points, func, keys, method, t_method):
     print(_fuzz.judge(func, keys, method, t_method, tag, d, got))
 
 
+@pytest.mark.parametrize("func,keys,kwargs", _fuzz.DIRECT, ids=[f"{f}-{'-'.join(map(str, kw.values()))}" for f, _, kw in _fuzz.DIRECT])
+def test_direct_functions_on_the_fuzz_domain(points, func, keys, kwargs):
+    tag, dtype, d = points
+    got = twin.by_reference_name(func, [d[k] for k in keys], dict(kwargs), dtype)
+    print(_fuzz.judge_direct(func, keys, kwargs, tag, d, got))
+
+
 @pytest.mark.parametrize("method", _fuzz.METHODS)
 def test_default_walk_is_the_exact_walk_bit_for_bit(points, method, monkeypatch):
     """The tree walk decides most steps by a sign test without a transcendental; `bisect_exact` evaluates the
