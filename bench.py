@@ -434,7 +434,15 @@ def main():
     sync()
     dist.barrier()
     sync()
-    t0 = time.perf_counter()  # CLOCK_MONOTONIC: one clock for every process of the node, so the ranks' stamps compare
+    # The ranks leave a gloo barrier hundreds of microseconds apart -- of the order of a strong-scaling step at N = 8 (0.65 ms),
+    # in a timed region of ~13 ms.  CLOCK_MONOTONIC is one clock for every process of the node: inside the bracket the ranks
+    # agree on an instant 10 ms ahead (the latest rank's clock, all-reduced) and spin until then, so that they START within
+    # microseconds of one another; a rank that arrives late starts at once (barrier_skew_ms shows it).
+    if dist.world > 1:
+        t_go = dist.reduce(time.perf_counter(), "max") + 10e-3
+        while time.perf_counter() < t_go:
+            pass
+    t0 = time.perf_counter()
     for k in range(args.steps):
         if not args.dry_run:
             _ffi.check(lib.ekm_event_record(dev, evs[k], None))  # same (default) stream the kernels are launched on

@@ -59,6 +59,28 @@ def bisect_sign_noise(func, inputs, kwargs, thresh, return_points=False):
     return (noisy, pts) if return_points else noisy
 
 
+def bisect_nan_rule_noise(func, inputs, kwargs, thresh):
+    """Points whose bisection visits a lattice temperature where the reference's NaN rule, `p - es < 1e-4 -> NaN`
+    (thermo.py:192-196, 229-232, 1283-1284), is decided by the rounding of es itself: |(p - es) - 1e-4| <= thresh * es on
+    the oracle's fp64 path (es at 313.16 K is 7384.176 Pa with an fp32 spacing of 4.9e-4 and an fp32 error of up to 0.02:
+    a pressure within that of it turns the search NaN or not by the last bits of es).  Either outcome is the
+    reference's there."""
+    with np.errstate(all="ignore"):
+        ept, p, m = _ept_and_p(func, inputs, kwargs)
+        meth = orc._EPT[m]
+        t = np.full(ept.size, orc.T0 - 20.0)
+        dt = 120.0
+        noisy = np.zeros(ept.size, dtype=bool)
+        for _ in range(12):
+            es = orc.saturation_vapour_pressure(t)
+            noisy |= np.abs((p - es) - 1e-4) <= thresh * es
+            st = orc._state(t=t, p=p)
+            dt /= 2.0
+            r = ept * np.exp(meth["gsat"](st, scale=-1.0)) - meth["thsat"](st)
+            t = t + np.sign(r) * dt
+    return noisy
+
+
 def newton_regime_boundary(func, inputs, kwargs, thresh):
     """Points whose c_te lies within relative `thresh` of a regime threshold (D(p), 1, 0.4); a tuple of
     thresholds gives a tuple of masks (c_te is formed once)."""
