@@ -160,6 +160,12 @@ def misses_explained(f, xs, got, want, tol, h=1e-6, unit=2.0 ** -24, factor=8.0)
         lo_e, hi_e = lo - width, hi + width
         ok_range = some & (got >= lo_e - tol * np.abs(lo_e)) & (got <= hi_e + tol * np.abs(hi_e))
         on_edge = edge & np.where(np.isnan(got), cn.any(axis=0), ok_range)
+        # ... and a DISCONTINUITY of the reference that is not a NaN edge: the Davies-Jones regime thresholds (c_te against
+        # D(p), 1, 0.4; thermo.py:1114-1128), across which the guess jumps -- by 25 K at 70 Pa.  kappa is finite but meaningless
+        # there (a secant through the jump); the value under test is explained if it lies inside the span of the outcomes
+        # that the +-h perturbations produce (no extension: both sides are finite), e.g. it IS the other regime's result.
+        in_span = ~nanmm & some & ~cn.any(axis=0) & (got >= lo - tol * np.abs(lo)) & (got <= hi + tol * np.abs(hi))
+        on_edge = on_edge | in_span
     return finite, on_edge
 
 

@@ -172,7 +172,7 @@ def judge(func, keys, method, t_method, tag, d, got):
     _record(what, "newton fuzz: points outside the atmospheric region (150 K <= tw <= 400 K, |step| <= 10 K) beyond the plain bar, all explained",
             int(out.sum()), lim_out, int((~phys).sum()))
     assert out.sum() <= lim_out, f"{what}: {int(out.sum())} relaxed points outside the atmospheric region (limit {lim_out:.0f})"
-    wellc = phys & (bar <= tol)
+    wellc = phys & (bar <= tol) & ~miss  # (`miss`: beyond its bar, explained above by a regime jump / NaN edge of the reference)
     worst = float(r[wellc].max()) if wellc.any() else 0.0
     line = (f"{what}: {n} points, NaN mismatches {int(nanmm.sum())} (on the reference's own NaN edges), atmospheric region "
             f"{int(phys.sum())} points worst {worst:.2e} ({rel_in} ill-conditioned beyond {rtol:g}), outside it {int(out.sum())} beyond "
