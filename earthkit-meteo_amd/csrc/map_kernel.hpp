@@ -828,10 +828,12 @@ int launch_map(int dev, void* stream, const ekm_operand* const* ins, void* const
   unsigned tiles = (unsigned)tuning_tiles_per_block();
   // an op that builds an LDS table per workgroup amortises it over more tiles (bisection: 4096 es values)
   // an op with an LDS table copies 32 KiB per workgroup from the device-resident table: a few tiles amortise that
-  // (0 = by op: the 512-thread tree walk of the IFS bisection copies 48 KiB per workgroup and takes 16 tiles -- 8 on hybrid
-  // levels, whose bands want the workgroups short --, the 32-KiB tables 8; profiles/r04_bisect_tree_walk.txt)
+  // (0 = by op: the tree walk of the IFS bisection copies 64 KiB per workgroup and takes 16 tiles -- 6 on hybrid
+  // levels, whose bands want the workgroups short: 2/4/6/8/16 tiles 3.25/3.11/3.07/3.19/3.48 ms --, the 32-KiB tables 8;
+  // profiles/r04_bisect_tree_walk.txt, profiles/r05_tree_walk.txt)
   unsigned table_tiles = (unsigned)tuning_table_tiles();
-  if (table_tiles == 0) table_tiles = OpThreads<Op, T>::tree && a.mode[NIN - 1] != EKM_HYBRID_FULL ? 16u : 8u;
+  if (table_tiles == 0)
+    table_tiles = !OpThreads<Op, T>::tree ? 8u : a.mode[NIN - 1] != EKM_HYBRID_FULL ? 16u : OpThreads<Op, T>::wide ? 6u : 8u;
   if (OpTable<Op>::elems > 0 && tiles < table_tiles) {
     const int cus = device_cus(dev);
     unsigned long long most = ntile / (4ull * (unsigned long long)(cus > 0 ? cus : 256));  // >= 4 workgroups per CU
