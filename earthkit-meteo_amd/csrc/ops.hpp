@@ -219,7 +219,7 @@ struct BisectTable {
         bisect_heap_fill<METHOD, heap_rec<METHOD, float>()>(tab, m);
       } else {
         bisect_es_fill(tab, m);
-        bisect_heap_fill<METHOD, heap_rec<METHOD, double>()>(reinterpret_cast<float*>(tab + kBisectLattice), m);
+        bisect_heap_fill<METHOD, heap_rec<METHOD, double>(), true>(reinterpret_cast<float*>(tab + kBisectLattice), m);
       }
     }
   }

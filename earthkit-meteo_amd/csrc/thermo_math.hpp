@@ -929,16 +929,28 @@ EKM_HD float heap_es(const float* __restrict__ tab, unsigned node) {
 // lattice index of heap node i at depth d (2^d <= i < 2^(d+1)), d <= 11
 EKM_HD int bisect_heap_lattice(int i, int d) { return (2 * (i - (1 << d)) + 1) << (11 - d); }
 
-template <int METHOD = EPT_IFS, int REC = 3>
+// F64: the tree the fp64 walk tests on.  Its exact steps take es from the fp64 lattice, so the tree holds THOSE values
+// rounded to float (6e-8) -- not the fp32 evaluation of es, which is 1e-6 .. 2.5e-6 off them: where p - es cancels (a parcel
+// near boiling: es = 0.9 p at 369 K and p0) that difference moved bolton39's test by more than its band (found by the
+// fuzz of theta_w, 5 of 1 M points two quanta off the stepwise search).
+template <int METHOD = EPT_IFS, int REC = 3, bool F64 = false>
 EKM_HD void bisect_heap_fill(float* __restrict__ tab, int i) {
   float es = 0.0f, a = 0.0f, L = 0.0f, t = 0.0f;
   if (i >= 1) {
     int d = 0;
     while ((2 << d) <= i) ++d;
-    t = bisect_lattice_t<float>(bisect_heap_lattice(i, d));
-    es = es_mixed(t);
-    a = bisect_second<METHOD>(es, 1.0f / t);  // IEEE division: once per device
-    L = (float)m_log2(double(t) * (1.0 / 273.16));
+    if (F64) {
+      const double td = bisect_lattice_t<double>(bisect_heap_lattice(i, d)), esd = es_mixed(td);
+      t = (float)td;
+      es = (float)esd;
+      a = (float)bisect_second<METHOD>(esd, 1.0 / td);
+      L = (float)m_log2(td * (1.0 / 273.16));
+    } else {
+      t = bisect_lattice_t<float>(bisect_heap_lattice(i, d));
+      es = es_mixed(t);
+      a = bisect_second<METHOD>(es, 1.0f / t);  // IEEE division: once per device
+      L = (float)m_log2(double(t) * (1.0 / 273.16));
+    }
   }
   if (REC == 4) {
     tab[4 * i] = es;
@@ -997,13 +1009,21 @@ EKM_HD float bisect_exact_residual(float es, float a, float w, float te, float t
     g = a * m_rcp(w);
   } else {
     const float ws = float(k::eps) * es * m_rcp(w);
-    g = m_fma(a * ws, m_fma(0.448f, ws, 1.0f), float(k::kappa) * m_log2(w * float(1.0 / k::p0)));
+    const float gs = a * ws;
+    g = m_fma(gs, m_fma(0.448f, ws, 1.0f), float(k::kappa) * m_log2(w * float(1.0 / k::p0)));
+    // an INFINITE theta_e (fp32 overflow of its exponential: a parcel near boiling): the reference's theta_e*exp(G_sat(-1))
+    // is +inf while that exponential is a nonzero (denormal) number and NaN (inf*0) once it underflows -- decided by the
+    // exponential ALONE, not by the one above that carries kappa*log2(v/p0) as well (found by the fuzz of the wet-bulb from
+    // the dewpoint: t 378.8 K, td 374.8 K, p 1162 hPa -> reference 373.13 K, the walk NaN)
+    if (EKM_ANY(!(te < std::numeric_limits<float>::infinity()))) {
+      if (!(te < std::numeric_limits<float>::infinity())) return te * m_exp2_denorm(gs * m_fma(0.448f, ws, 1.0f));
+    }
   }
   return m_fms(te, METHOD == EPT_IFS ? m_exp2(g) : m_exp2_denorm(g), tm);
 }
 
 // WS: test ws >= kB35WsExact at every node (A/B only: both walks ask once, of the hottest node they visited)
-template <int METHOD, bool WS = false>
+template <int METHOD, bool WS = false, bool F64 = false>
 EKM_HD float bisect_fast_test(float es, float a, float u, float p, float kl, float& w, float thr0, bool& amb) {
   float D, scale;  // D: MINUS the quantity of the comments above (bisect_heap_child takes it so); scale: |a_m| resp. its
   bool big_ws = false;  // counterpart -- the part of the band that goes with the size of the exponent
@@ -1027,8 +1047,12 @@ EKM_HD float bisect_fast_test(float es, float a, float u, float p, float kl, flo
     const float ees = float(k::eps) * es;
     scale = (a * ees) * m_fma(0.448f, ees, w);
     const float v2 = w * w;
-    D = m_fms(v2, m_fnma(float(k::kappa), m_log2(w * float(1.0 / k::p0)), u), scale);
+    const float X = m_fnma(float(k::kappa), m_log2(w * float(1.0 / k::p0)), u);
+    D = m_fms(v2, X, scale);
     thr0 = float(2.0 * kHeapTau0) * v2;  // the band in units of v^2 here (log2 of a small v adds its own rounding)
+    // the fp64 walk tests on p and es ROUNDED to float: w = p - es is off by up to 1.2e-7*p, which where it cancels is
+    // more than the band above knows of -- dD = dw*(2*w*|X| + kappa/ln2*w + |a|*eps*es)
+    if (F64) thr0 = m_fma(1.5e-7f * p, m_fma(w, m_fma(2.0f, __builtin_fabsf(X), 0.5f), __builtin_fabsf(a) * ees), thr0);
   }
   amb = !(__builtin_fabsf(D) > m_fma(__builtin_fabsf(scale), float(METHOD == EPT_IFS ? kHeapTau1 : 2.0 * kHeapTau1), thr0));  // NaN: ambiguous
   if (METHOD == EPT_BOLTON35 && WS) amb = amb || big_ws;
@@ -1185,6 +1209,8 @@ EKM_HD T bisect_exact_residual64(T es, T tm, T te, T p, T kl) {
   } else {
     const T ws = T(k::eps) * es * rv;
     g = m_fma(a * ws, m_fma(T(0.448), ws, T(1)), T(k::kappa) * m_log2(v * T(1.0 / k::p0)));
+    if (!(te < T(std::numeric_limits<double>::infinity())))  // an infinite theta_e: see bisect_exact_residual
+      return te * m_exp2_denorm((a * ws) * m_fma(T(0.448), ws, T(1)));
   }
   return m_fms(te, METHOD == EPT_IFS ? m_exp2(g) : m_exp2_denorm(g), tm);
 }
@@ -1246,7 +1272,7 @@ EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (
       const float es = nd.es, a = nd.a;
       const float u = nd.L - ltef[j];
       float w;
-      D[j] = bisect_fast_test<METHOD, false>(es, a, u, pf[j], klf[j], w, thr0[j], amb[j]);  // (the band is wide enough for
+      D[j] = bisect_fast_test<METHOD, false, true>(es, a, u, pf[j], klf[j], w, thr0[j], amb[j]);  // (the band is wide enough for
       any |= EKM_WAVE_MASK(amb[j]);                                                         //  the inputs' rounding to float)
       amb[j] = amb[j] || all_exact;
     }

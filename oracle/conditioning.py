@@ -39,6 +39,14 @@ def bisect_sign_noise(func, inputs, kwargs, thresh, return_points=False):
     happens, shape (n, 12), NaN where the step is decided cleanly: a search whose sign flips at such
     a point ends within one quantum of it (it converges back onto it from the other side)."""
     with np.errstate(all="ignore"):
+        # the arithmetic under test: where one of the two terms' exponential factors -- exp(G_sat(-1)), th_sat/t --
+        # lands within a few quanta of the dtype's smallest subnormal while the other term is subnormal too, whether
+        # that factor rounds to zero or to one quantum (a 1e-6 difference in es moves bolton35's exponent by 0.3 where
+        # p - es is a fraction of a pascal) decides between "0 - 0: stay on this node" and "move on": the reference's
+        # own rounding (t 316.68 K, q 1.083e-4, p 7393.3145 Pa, bolton35: th_sat = 313.16 * 2^-149.9)
+        in_dt = np.result_type(*[np.asarray(x).dtype for x in inputs])
+        fin = np.finfo(in_dt if in_dt.kind == "f" else np.float64)
+        sub, tiny = float(fin.smallest_subnormal), float(fin.tiny)
         ept, p, m = _ept_and_p(func, inputs, kwargs)
         meth = orc._EPT[m]
         t = np.full(ept.size, orc.T0 - 20.0)
@@ -50,8 +58,19 @@ def bisect_sign_noise(func, inputs, kwargs, thresh, return_points=False):
             dt /= 2.0
             g = meth["gsat"](st, scale=-1.0)
             th = meth["thsat"](st)
-            r = ept * np.exp(g) - th
+            fa = np.exp(g)
+            r = ept * fa - th
             here = np.abs(r) <= thresh * np.abs(th)
+            # ... or by es itself: the residual's sign changes when es moves by `thresh` (the fp32 evaluations of es differ
+            # by a few 1e-6; through exp(-G) that is G * d ln qs/d ln es times as much -- 2.5e-5 of the residual's terms at
+            # 371 K and p0, where a theta_w search with theta_e = 2e5 K has r = +3.5e-6 * th_sat in the reference)
+            dtn = thresh * orc.saturation_vapour_pressure(t) / orc.saturation_vapour_pressure_slope(t)
+            for sg in (1.0, -1.0):
+                s2 = orc._state(t=t + sg * dtn, p=p)
+                r2 = ept * np.exp(meth["gsat"](s2, scale=-1.0)) - meth["thsat"](s2)
+                here |= np.isfinite(r) & np.isfinite(r2) & (np.sign(r2) != np.sign(r))
+            fb = th / t
+            here |= ((fa > sub / 8) & (fa < 16 * sub) & (np.abs(th) < tiny)) | ((fb > sub / 8) & (fb < 16 * sub) & (np.abs(ept * fa) < tiny))
             noisy |= here
             if return_points:
                 pts[here, it] = t[here]

@@ -48,6 +48,17 @@ T_METHODS = ("bisect", "newton")
 FUNCS = (("temperature_on_moist_adiabat", ("ept", "p")),
          ("wet_bulb_temperature_from_specific_humidity", ("t", "q", "p")))
 CASES = [(f, keys, m, tm) for f, keys in FUNCS for m in METHODS for tm in T_METHODS]
+# the other three callers of the same inversions (theta_e from the dewpoint; theta_w: the inversion at p0), on the first
+# MORE_POINTS points of the same draw
+FUNCS_MORE = (("wet_bulb_temperature_from_dewpoint", ("t", "td", "p")),
+              ("wet_bulb_potential_temperature_from_specific_humidity", ("t", "q", "p")),
+              ("wet_bulb_potential_temperature_from_dewpoint", ("t", "td", "p")))
+CASES_MORE = [(f, keys, m, tm) for f, keys in FUNCS_MORE for m in METHODS for tm in T_METHODS]
+MORE_POINTS = 1 << 18
+
+
+def head(d, n=MORE_POINTS):
+    return {k: v[:n] for k, v in d.items()}
 
 
 def make(n=N_POINTS, seed=SEED, dtype=np.float32):
@@ -110,8 +121,9 @@ def judge(func, keys, method, t_method, tag, d, got):
         bar = np.maximum(tol, 4.0 * delta)
     # the operands of the reference's own Newton step, from the fp64 oracle
     with np.errstate(all="ignore"):
-        e64 = ins64[0] if func == "temperature_on_moist_adiabat" else orc.ept_from_specific_humidity(*ins64, method=method)
-        e64, p64 = np.broadcast_arrays(e64, ins64[-1])
+        # theta_e and the pressure the inversion runs at (p0 for the theta_w functions), as the reference forms them
+        e64, p64, _ = conditioning._ept_and_p(func, ins64, kwargs)
+        e64, p64 = e64.reshape(w64.shape), p64.reshape(w64.shape)
         tw64, parts = orc._t_on_ma_newton(orc._EPT[method], e64.ravel().copy(), p64.ravel().copy(), return_parts=True)
         guess = parts["guess"].reshape(w64.shape)
         tw_pre = guess - ((parts["f"] - parts["c_te"]) / (parts["f"] * parts["dlnf"])).reshape(w64.shape)  # before `tw <= 0 -> NaN`
@@ -149,8 +161,19 @@ def judge(func, keys, method, t_method, tag, d, got):
     _record(what, "newton fuzz: NaN on one side where |tw| is within its rounding bound of the tw <= 0 edge", int(edge_zero.sum()),
             max(3, 1e-5 * n), n)
     assert edge_zero.sum() <= max(3, 1e-5 * n), (what, int(edge_zero.sum()))
+    # the step's DENOMINATOR is rounding noise: dlnf = -lambda*(1/tw + ...) cancels (bolton35: to 1e-5 of its terms) and
+    # the first-order bound of its own rounding, STEP_FACTOR*UNIT*eu*max(lambda/guess, |d ln f/d tw|), is a quarter of |dlnf|
+    # or more -- the bound above is first order in that ratio and says nothing there; the reference's fp32 and fp64 runs
+    # give 1628 K and 1049 K for t 186.37 K, td 154.76 K, p 96.76 Pa (dlnf 1.5e-7 / 2.5e-7 against terms of 2e-2), a kernel
+    # whose dlnf comes out at 1e-9 gives 2e5 K.  Never an atmospheric result; counted and limited
+    with np.errstate(all="ignore"):
+        edge_den = STEP_FACTOR * UNIT[tag] * eu * np.maximum(orc.LAMBDA / np.abs(guess), at) >= 0.25 * ad
+        edge_den &= ~phys & (nanmm | (r > bar))
+    _record(what, "newton fuzz: deviations where the step's denominator dlnf is within 4x its own rounding bound of zero (never an atmospheric result)",
+            int(edge_den.sum()), max(3, 1e-5 * n), n)
+    assert edge_den.sum() <= max(3, 1e-5 * n), (what, int(edge_den.sum()))
     # beyond every bar: the reference's conditioning with respect to its inputs must explain it (kappa / NaN edges)
-    miss = (nanmm | (r > bar)) & ~edge_es & ~edge_zero
+    miss = (nanmm | (r > bar)) & ~edge_es & ~edge_zero & ~edge_den
     idx = np.flatnonzero(miss)
     if idx.size:
         fin, edge = conditioning.misses_explained(lambda *x: f(*x, **kwargs), [a[idx] for a in ins64], g64[idx], w64[idx],

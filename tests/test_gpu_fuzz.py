@@ -39,6 +39,17 @@ def test_fuzz_against_the_oracle(ek, points, dev_points, func, keys, method, t_m
     print(_fuzz.judge(func, keys, method, t_method, tag, d, got))
 
 
+@pytest.mark.parametrize("func,keys,method,t_method", _fuzz.CASES_MORE,
+                         ids=[f"{'-'.join(f.split('_')[:3] + f.split('_')[-1:])}-{m}-{tm}" for f, _, m, tm in _fuzz.CASES_MORE])
+def test_fuzz_of_the_other_callers_of_the_inversions(ek, points, func, keys, method, t_method):
+    """theta_e from the dewpoint and theta_w (the inversion at p0) -- NumPy in, NumPy out: the streamed host path."""
+    tag, dtype, d = points
+    d = _fuzz.head(d)
+    got = getattr(ek.thermo, func)(*[d[k] for k in keys], ept_method=method, t_method=t_method)
+    assert isinstance(got, np.ndarray)
+    print(_fuzz.judge(func, keys, method, t_method, tag, d, got))
+
+
 @pytest.mark.parametrize("func,keys,kwargs", _fuzz.DIRECT, ids=[f"{f}-{'-'.join(map(str, kw.values()))}" for f, _, kw in _fuzz.DIRECT])
 def test_direct_functions_on_the_fuzz_domain(ek, points, dev_points, func, keys, kwargs):
     tag, dtype, d = points
@@ -62,7 +73,7 @@ def _same_bits(a, b):
 def test_default_walk_is_the_exact_walk_on_the_fuzz_domain(ek, points, dev_points, method):
     tag, dtype, d = points
     try:
-        for func, keys in _fuzz.FUNCS:
+        for func, keys in _fuzz.FUNCS + _fuzz.FUNCS_MORE:
             ins = [dev_points[k] for k in keys]
             _exact(False)
             fast = getattr(ek.thermo, func)(*ins, ept_method=method, t_method="bisect")
@@ -117,4 +128,11 @@ def test_default_walk_is_the_exact_walk_on_eight_levels_of_the_benchmark_field(e
 def test_bolton35_stays_on_the_node_where_both_terms_underflow(ek, dtype, t, q, p, expect):
     got = ek.thermo.wet_bulb_temperature_from_specific_humidity(np.array([t], dtype), np.array([q], dtype), np.array([p], dtype),
                                                                 ept_method="bolton35", t_method="bisect")
+    assert got.dtype == dtype and abs(float(got[0]) - expect) < 1e-4, got
+
+
+@pytest.mark.parametrize("dtype,t,td,p,expect", __import__("test_hosttwin_fuzz").B39_INFINITE_EPT)
+def test_bolton39_with_an_infinite_theta_e(ek, dtype, t, td, p, expect):
+    got = ek.thermo.wet_bulb_temperature_from_dewpoint(np.array([t], dtype), np.array([td], dtype), np.array([p], dtype),
+                                                       ept_method="bolton39", t_method="bisect")
     assert got.dtype == dtype and abs(float(got[0]) - expect) < 1e-4, got

@@ -30,6 +30,15 @@ def test_fuzz_against_the_oracle(points, func, keys, method, t_method):
     print(_fuzz.judge(func, keys, method, t_method, tag, d, got))
 
 
+@pytest.mark.parametrize("func,keys,method,t_method", _fuzz.CASES_MORE,
+                         ids=[f"{'-'.join(f.split('_')[:3] + f.split('_')[-1:])}-{m}-{tm}" for f, _, m, tm in _fuzz.CASES_MORE])
+def test_fuzz_of_the_other_callers_of_the_inversions(points, func, keys, method, t_method):
+    tag, dtype, d = points
+    d = _fuzz.head(d)
+    got = twin.by_reference_name(func, [d[k] for k in keys], dict(ept_method=method, t_method=t_method), dtype)
+    print(_fuzz.judge(func, keys, method, t_method, tag, d, got))
+
+
 @pytest.mark.parametrize("func,keys,kwargs", _fuzz.DIRECT, ids=[f"{f}-{'-'.join(map(str, kw.values()))}" for f, _, kw in _fuzz.DIRECT])
 def test_direct_functions_on_the_fuzz_domain(points, func, keys, kwargs):
     tag, dtype, d = points
@@ -42,7 +51,7 @@ def test_default_walk_is_the_exact_walk_bit_for_bit(points, method, monkeypatch)
     """The tree walk decides most steps by a sign test without a transcendental; `bisect_exact` evaluates the
     reference's own residual at every step.  Same bits on every point of the fuzz domain (the env var is read per call)."""
     tag, dtype, d = points
-    for func, keys in _fuzz.FUNCS:
+    for func, keys in _fuzz.FUNCS + _fuzz.FUNCS_MORE:
         ins = [d[k] for k in keys]
         kw = dict(ept_method=method, t_method="bisect")
         monkeypatch.delenv("EKM_TWIN_BISECT_EXACT", raising=False)
@@ -73,4 +82,20 @@ B35_UNDERFLOW = [
 def test_bolton35_stays_on_the_node_where_both_terms_underflow(dtype, t, q, p, expect):
     got = twin.by_reference_name("wet_bulb_temperature_from_specific_humidity", [np.array([t]), np.array([q]), np.array([p])],
                                  dict(ept_method="bolton35", t_method="bisect"), dtype)
+    assert abs(float(got[0]) - expect) < 1e-4, got
+
+
+# (t, td, p) -> wet_bulb_temperature_from_dewpoint(..., "bolton39", "bisect"), recorded from the reference itself: theta_e
+# overflows fp32 (a parcel near boiling); the reference's residual is +inf while exp(G_sat(-1)) is a nonzero (denormal) number
+# and NaN once that underflows -- here it does not, down to the last node (found by tools/fuzz_sweep.py, seed 1000).
+B39_INFINITE_EPT = [
+    (np.float32, 378.817, 374.80237, 116185.484, 373.1307),
+    (np.float64, 378.817, 374.80237, 116185.484, 373.13070313),
+]
+
+
+@pytest.mark.parametrize("dtype,t,td,p,expect", B39_INFINITE_EPT)
+def test_bolton39_with_an_infinite_theta_e(dtype, t, td, p, expect):
+    got = twin.by_reference_name("wet_bulb_temperature_from_dewpoint", [np.array([t]), np.array([td]), np.array([p])],
+                                 dict(ept_method="bolton39", t_method="bisect"), dtype)
     assert abs(float(got[0]) - expect) < 1e-4, got

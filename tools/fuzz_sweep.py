@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The wide-domain fuzz of tests/_fuzz.py with other seeds and more points than the suites run (they take one seed of
-2^20 points): every theta_e method x {bisect, newton} x {fp32, fp64} x {from (theta_e, p), from (t, q, p)} on the GPU
+2^20 points): every theta_e method x {bisect, newton} x {fp32, fp64} x {from (theta_e, p), from (t, q, p), from (t, td, p), theta_w from both} on the GPU
 against the oracle, judged by the same rules (tests/_fuzz.py::judge raises on the first real miss), plus the default walk
 against the exact walk bit for bit.
 
@@ -15,26 +15,55 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "earthkit-meteo_amd"), os.path.join(ROOT, "tests")]
 
-import ekm_hip  # noqa: E402
-from ekm_hip import _ffi  # noqa: E402
-
 import _fuzz  # noqa: E402
+
+
+def twin_sweep(a):
+    """The same sweep on the host twin (the kernels' templates compiled for the CPU; no GPU): --twin."""
+    import _hosttwin as twin
+
+    t0 = time.time()
+    for s in range(a.seeds):
+        seed = a.first_seed + 17 * s
+        for tag, dtype in (("f32", np.float32), ("f64", np.float64)):
+            d = _fuzz.make(a.n, seed, dtype)
+            for func, keys, method, tm in _fuzz.CASES + _fuzz.CASES_MORE:
+                ins, kw = [d[k] for k in keys], dict(ept_method=method, t_method=tm)
+                os.environ.pop("EKM_TWIN_BISECT_EXACT", None)
+                got = twin.by_reference_name(func, ins, kw, dtype)
+                line = _fuzz.judge(func, keys, method, tm, tag, d, got)
+                if tm == "bisect":
+                    os.environ["EKM_TWIN_BISECT_EXACT"] = "1"
+                    e = twin.by_reference_name(func, ins, kw, dtype)
+                    os.environ.pop("EKM_TWIN_BISECT_EXACT", None)
+                    diff = ~((got == e) | (np.isnan(got) & np.isnan(e)))
+                    assert not diff.any(), (func, method, tag, seed, int(diff.sum()), np.flatnonzero(diff)[:4], got[diff][:4], e[diff][:4])
+                    line += "; default walk == exact walk on every point"
+                print(f"seed {seed} {line}", flush=True)
+    print(f"fuzz sweep (host twin): {a.seeds} seeds x {a.n} points x {2 * len(_fuzz.CASES + _fuzz.CASES_MORE)} cases: no real miss, {time.time() - t0:.0f} s")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=3)
     ap.add_argument("--n", type=int, default=1 << 22)
+    ap.add_argument("--first-seed", type=int, default=1000)
+    ap.add_argument("--twin", action="store_true", help="run the host twin instead of the GPU")
     a = ap.parse_args()
     np.seterr(all="ignore")
+    if a.twin:
+        return twin_sweep(a)
+    import ekm_hip
+    from ekm_hip import _ffi
+
     lib = _ffi.lib()
     t0 = time.time()
     for s in range(a.seeds):
-        seed = 1000 + 17 * s
+        seed = a.first_seed + 17 * s
         for tag, dtype in (("f32", np.float32), ("f64", np.float64)):
             d = _fuzz.make(a.n, seed, dtype)
             dd = {k: ekm_hip.to_device(v) for k, v in d.items()}
-            for func, keys, method, tm in _fuzz.CASES:
+            for func, keys, method, tm in _fuzz.CASES + _fuzz.CASES_MORE:
                 ins = [dd[k] for k in keys]
                 out = getattr(ekm_hip.thermo, func)(*ins, ept_method=method, t_method=tm)
                 got = out.to_host()
@@ -52,7 +81,7 @@ def main():
                 print(f"seed {seed} {line}", flush=True)
             for v in dd.values():
                 v.free()
-    print(f"fuzz sweep: {a.seeds} seeds x {a.n} points x 24 cases: no real miss, {time.time() - t0:.0f} s")
+    print(f"fuzz sweep: {a.seeds} seeds x {a.n} points x {2 * len(_fuzz.CASES + _fuzz.CASES_MORE)} cases: no real miss, {time.time() - t0:.0f} s")
 
 
 if __name__ == "__main__":
