@@ -161,6 +161,21 @@ def judge(func, keys, method, t_method, tag, d, got):
     _record(what, "newton fuzz: NaN on one side where |tw| is within its rounding bound of the tw <= 0 edge", int(edge_zero.sum()),
             max(3, 1e-5 * n), n)
     assert edge_zero.sum() <= max(3, 1e-5 * n), (what, int(edge_zero.sum()))
+    # the reference's `p - es < 1e-4 -> NaN` rule (thermo.py:192-196, 229-232) inside the Newton path -- es(te) in the
+    # regime-1 guess, es(guess) in the step -- decided by the last bits of es: NaN on either side is the reference's own
+    # rounding (t 234.566 K, q 2.339e-5, p 15.178763 Pa, bolton35: es(te = 233.9 K) is p - 1e-4 to 2e-6 of itself).  The
+    # bisection's twin of this edge is conditioning.bisect_nan_rule_noise
+    with np.errstate(all="ignore"):
+        te_k = (e64 * np.power(p64 / orc.p0, orc.kappa)).reshape(w64.shape)
+        th_es = 8e-6 if tag == "f32" else 1e-13
+        edge_rule = np.zeros(n, bool)
+        for x in (te_k, guess):
+            esx = orc.saturation_vapour_pressure(x)
+            edge_rule |= np.abs((p64 - esx) - 1e-4) <= th_es * esx
+        edge_rule &= nanmm
+    _record(what, "newton fuzz: NaN on one side where p - es(te) or p - es(guess) is within rounding of the 1e-4 threshold", int(edge_rule.sum()),
+            max(3, 1e-5 * n), n)
+    assert edge_rule.sum() <= max(3, 1e-5 * n), (what, int(edge_rule.sum()))
     # the step's DENOMINATOR is rounding noise: dlnf = -lambda*(1/tw + ...) cancels (bolton35: to 1e-5 of its terms) and
     # the first-order bound of its own rounding, STEP_FACTOR*UNIT*eu*max(lambda/guess, |d ln f/d tw|), is a quarter of |dlnf|
     # or more -- the bound above is first order in that ratio and says nothing there; the reference's fp32 and fp64 runs
@@ -173,7 +188,7 @@ def judge(func, keys, method, t_method, tag, d, got):
             int(edge_den.sum()), max(3, 1e-5 * n), n)
     assert edge_den.sum() <= max(3, 1e-5 * n), (what, int(edge_den.sum()))
     # beyond every bar: the reference's conditioning with respect to its inputs must explain it (kappa / NaN edges)
-    miss = (nanmm | (r > bar)) & ~edge_es & ~edge_zero & ~edge_den
+    miss = (nanmm | (r > bar)) & ~edge_es & ~edge_zero & ~edge_den & ~edge_rule
     idx = np.flatnonzero(miss)
     if idx.size:
         fin, edge = conditioning.misses_explained(lambda *x: f(*x, **kwargs), [a[idx] for a in ins64], g64[idx], w64[idx],
