@@ -286,3 +286,22 @@ def judge_direct(func, keys, kwargs, tag, d, got):
     line = f"{what}: {r.size} points, worst {float(r[r <= tol].max()) if (r <= tol).any() else 0.0:.2e}, {relaxed} at 4*delta, inf-vs-huge {int(infmm.sum())}"
     CENSUS.append(line)
     return line
+
+
+# the fused pipelines (BASELINE configs 3 and 5) on the same domain: every output judged as the separate function is
+FUSED = {"pipeline_svp_td_rh": ("es", "td", "rh"), "pipeline_full": ("th", "es", "rh", "td", "the", "tw")}
+FUSED_AS = {"th": ("potential_temperature", ("t", "p"), {}), "es": ("saturation_vapour_pressure", ("t",), {"phase": "mixed"}),
+            "rh": ("relative_humidity_from_specific_humidity", ("t", "q", "p"), {}),
+            "td": ("dewpoint_from_specific_humidity", ("q", "p"), {}),
+            "the": ("ept_from_specific_humidity", ("t", "q", "p"), {"method": "ifs"})}
+
+
+def judge_fused(name, tag, d, outs):
+    lines = []
+    for key, got in zip(FUSED[name], outs):
+        if key == "tw":
+            lines.append(judge("wet_bulb_temperature_from_specific_humidity", ("t", "q", "p"), "ifs", "newton", tag, d, got))
+        else:
+            func, keys, kwargs = FUSED_AS[key]
+            lines.append(judge_direct(func, keys, kwargs, tag, d, got))
+    return "\n".join(f"{name}: {ln}" for ln in lines)

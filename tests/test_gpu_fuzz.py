@@ -59,6 +59,17 @@ def test_direct_functions_on_the_fuzz_domain(ek, points, dev_points, func, keys,
     print(_fuzz.judge_direct(func, keys, kwargs, tag, d, got))
 
 
+@pytest.mark.parametrize("name", sorted(_fuzz.FUSED))
+def test_fused_pipelines_on_the_fuzz_domain(ek, points, dev_points, name):
+    """BASELINE configs 3 and 5 far outside the benchmark distribution: every output held to the separate function's bar."""
+    tag, dtype, d = points
+    outs = getattr(ek.thermo, name)(*[dev_points[k] for k in ("t", "q", "p")])
+    got = [o.to_host() for o in outs]
+    for o in outs:
+        o.free()
+    print(_fuzz.judge_fused(name, tag, d, got))
+
+
 def _exact(on):
     from ekm_hip import _ffi
 

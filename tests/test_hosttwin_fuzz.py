@@ -19,7 +19,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(twin.PATH), reason="host twin
 @pytest.fixture(scope="module", params=["f32", "f64"])
 def points(request):
     dtype = np.float32 if request.param == "f32" else np.float64
-    return request.param, dtype, _fuzz.make(dtype=dtype)
+    return request.param, dtype, _fuzz.make(n=_fuzz.N_POINTS // 2, dtype=dtype)  # (the -m gpu twin of this file runs all 2^20)
 
 
 @pytest.mark.parametrize("func,keys,method,t_method", _fuzz.CASES,
@@ -44,6 +44,13 @@ def test_direct_functions_on_the_fuzz_domain(points, func, keys, kwargs):
     tag, dtype, d = points
     got = twin.by_reference_name(func, [d[k] for k in keys], dict(kwargs), dtype)
     print(_fuzz.judge_direct(func, keys, kwargs, tag, d, got))
+
+
+@pytest.mark.parametrize("name", sorted(_fuzz.FUSED))
+def test_fused_pipelines_on_the_fuzz_domain(points, name):
+    tag, dtype, d = points
+    outs = twin.by_reference_name(name, [d[k] for k in ("t", "q", "p")], {}, dtype)
+    print(_fuzz.judge_fused(name, tag, d, outs))
 
 
 @pytest.mark.parametrize("method", _fuzz.METHODS)
