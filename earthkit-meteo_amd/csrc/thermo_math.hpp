@@ -666,6 +666,14 @@ EKM_HD T lcl_t(T t, T td) {  // thermo.py:923-968
   return T(56.0) + m_rcp(m_fma(m_log(m_div(t, td)), T(1.0 / 800), m_rcp(td - T(56))));
 }
 
+// exp2 whose result may be a denormal (v_exp_f32 flushes those to zero; the reference's exp / pow round them).  Needed
+// where the reference's own arithmetic meets such a value again: the exact step of the bolton35 search (its two terms
+// are compared where both are that small) and bolton35's th_sat and theta_e (a denormal (p0/p)^(kappa*(1 - 0.28*w)) times an
+// overflowed exponential is inf in the reference, 0*inf = NaN only once the power has gone to zero altogether).
+EKM_HD float m_exp2_denorm(float x) { return x < -100.0f ? m_exp2(x + 64.0f) * 0x1p-64f : m_exp2(x); }
+EKM_HD double m_exp2_denorm(double x) { return m_exp2(x); }
+EKM_FD fd64<F> m_exp2_denorm(fd64<F> x) { return m_exp2(x); }
+
 // ---- equivalent potential temperature (thermo.py:1020-1323) ------------------
 // HAVE_Q: humidity given as specific humidity q (td derived from it,
 // thermo.py:1036-1037); otherwise as dewpoint td.
@@ -687,7 +695,7 @@ EKM_HD T ept(T t, T hum, T p) {
   const T tl = lcl_t<LCL_BOLTON>(t, td);
   const T w = HAVE_Q ? w_from_q(q) : w_from_e(es_water(td), p, T(k::eps_default));
   if (METHOD == EPT_BOLTON35) {  // thermo.py:1205-1213
-    const T th = t * m_pow(m_div(T(k::p0), p), T(k::kappa) * (T(1) - T(0.28) * w));
+    const T th = t * m_exp2_denorm((T(k::kappa) * (T(1) - T(0.28) * w)) * m_log2(m_div(T(k::p0), p)));  // (a power that keeps its denormals)
     return th * m_exp(m_div(T(2675.0) * w, tl));
   }
   // bolton39, thermo.py:1268-1278
@@ -695,14 +703,6 @@ EKM_HD T ept(T t, T hum, T p) {
   const T th = theta(t, p - e) * m_pow(m_div(t, tl), T(0.28) * w);
   return th * m_exp((m_div(T(3036.0), tl) - T(1.78)) * w * (T(1) + T(0.448) * w));
 }
-
-// exp2 whose result may be a denormal (v_exp_f32 flushes those to zero; the reference's exp / pow round them).  Needed
-// where the reference's own arithmetic meets such a value again: the exact step of the bolton35 search (its two terms
-// are compared where both are that small) and bolton35's th_sat (a denormal th_sat times an overflowed exp(G) is inf in
-// the reference, 0*inf = NaN only once th_sat has gone to zero altogether).
-EKM_HD float m_exp2_denorm(float x) { return x < -100.0f ? m_exp2(x + 64.0f) * 0x1p-64f : m_exp2(x); }
-EKM_HD double m_exp2_denorm(double x) { return m_exp2(x); }
-EKM_FD fd64<F> m_exp2_denorm(fd64<F> x) { return m_exp2(x); }
 
 // th_sat and G_sat(scale) of the saturated parcel (thermo.py:1177-1182,
 // 1215-1224, 1280-1295).  bolton39 masks es where p - es < 1e-4.

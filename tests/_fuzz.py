@@ -68,7 +68,19 @@ def make(n=N_POINTS, seed=SEED, dtype=np.float32):
              q=np.exp(r.uniform(np.log(1e-7), np.log(0.9), n)),
              ept=np.exp(r.uniform(np.log(150.0), np.log(3000.0), n)))
     d["td"] = d["t"] - r.uniform(0.0, 60.0, n)  # (drawn last: the four above are what they were before this one existed)
-    return {k: v.astype(dtype) for k, v in d.items()}
+    d["r"] = r.uniform(0.5, 120.0, n)          # relative humidity in per cent (drawn after td, for the same reason)
+    d = {k: v.astype(dtype) for k, v in d.items()}
+    # the other operands the 39 functions take (tests/golden/_case_table.py), derived from the draws in the dtype under test
+    from oracle import thermo_oracle as orc
+    with np.errstate(all="ignore"):
+        d["tc"] = (d["t"] - dtype(273.16)).astype(dtype)
+        d["w"] = (d["q"] / (1 - d["q"])).astype(dtype)
+        d["e"] = orc.vapour_pressure_from_specific_humidity(d["q"], d["p"]).astype(dtype)
+        d["es"] = orc.saturation_vapour_pressure(d["t"]).astype(dtype)
+        d["th"] = orc.potential_temperature(d["t"], d["p"]).astype(dtype)
+        d["t2"] = (d["t"] - dtype(10.0)).astype(dtype)
+        d["p2"] = (d["p"] * dtype(0.8)).astype(dtype)
+    return d
 
 
 def judge(func, keys, method, t_method, tag, d, got):
@@ -248,6 +260,21 @@ DIRECT = [
 ]
 
 
+def _case_table():
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("_case_table", os.path.join(os.path.dirname(__file__), "golden", "_case_table.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.case_table()
+
+
+# every other closed-form case of the 39 functions x variants (tests/golden/_case_table.py), on MORE_POINTS points
+DIRECT_REST = [(f, tuple(a), kw) for f, a, kw in _case_table()
+               if kw.get("t_method") not in ("bisect", "newton") and (f, tuple(a), kw) not in DIRECT]
+
+
 def judge_direct(func, keys, kwargs, tag, d, got):
     from oracle import thermo_oracle as orc
 
@@ -256,10 +283,21 @@ def judge_direct(func, keys, kwargs, tag, d, got):
     with np.errstate(all="ignore"):
         want = getattr(orc, func)(*ins, **kwargs)
         ref64 = getattr(orc, func)(*[a.astype(np.float64) for a in ins], **kwargs) if tag == "f32" else None
-    got = np.asarray(got)
+    ins64 = [a.astype(np.float64) for a in ins]
+    if isinstance(want, tuple):  # lcl: (t_lcl, p_lcl)
+        assert isinstance(got, tuple) and len(got) == len(want), (what, type(got))
+        return "; ".join(_judge_direct(f"{what}[{k}]", tag, d[keys[0]].dtype, got[k], want[k], None if ref64 is None else ref64[k],
+                                       lambda *x, k=k: getattr(orc, func)(*x, **kwargs)[k], ins64) for k in range(len(want)))
+    return _judge_direct(what, tag, d[keys[0]].dtype, got, want, ref64, lambda *x: getattr(orc, func)(*x, **kwargs), ins64)
+
+
+def _judge_direct(what, tag, in_dtype, got, want, ref64, f64, ins64):
+    from oracle import conditioning
+
+    got, want = np.asarray(got), np.asarray(want)
     # (theta_w "direct" in fp32: the reference's result comes back as float64 through the float64 coefficient lists of its
     # namespace's polyval -- a property of that third-party helper; the kernels keep the input dtype, values are compared)
-    assert got.dtype == d[keys[0]].dtype and got.shape == want.shape, (what, got.dtype, got.shape)
+    assert got.dtype == in_dtype and got.shape == want.shape, (what, got.dtype, got.shape)
     g, w = got.astype(np.float64), want.astype(got.dtype).astype(np.float64)
     assert np.array_equal(np.isnan(g), np.isnan(w)), f"{what}: NaN pattern differs at {np.flatnonzero(np.isnan(g) != np.isnan(w))[:4]}"
     big = float(np.finfo(got.dtype).max) / 1e2
@@ -282,7 +320,18 @@ def judge_direct(func, keys, kwargs, tag, d, got):
     lim = max(3, 1e-2 * r.size)  # (saturated parcels at p < es(t): mixing ratios of 1-1e3 in exponents, the reference's fp32 run itself is off)
     _record(what, "direct functions on the fuzz domain: points at max(rtol, 4*delta)", relaxed, lim, r.size)
     assert relaxed <= lim, f"{what}: {relaxed} points beyond {tol:g} (limit {lim:.0f})"
-    assert not (r > bar).any(), f"{what}: rel err {r[r > bar].max():.3e} beyond max({tol:g}, 4*delta) at {np.flatnonzero(r > bar)[:4]}"
+    # beyond max(rtol, 4*delta): the function's own conditioning must explain it -- ws = eps*es/(p - es) and its relatives
+    # where p - es cancels amplify the 2.5e-6 of an fp32 es by p/(p - es); kappa (oracle/conditioning.py::amplification,
+    # from the fp64 oracle alone) sees that as the sensitivity to t
+    idx = np.flatnonzero(r > bar)
+    if idx.size:
+        fin, edge = conditioning.misses_explained(f64, [a[idx] for a in ins64], g[idx], w[idx], tol, unit=UNIT[tag], factor=KAPPA_FACTOR)
+        ok = fin | edge
+        assert ok.all(), (f"{what}: rel err {r[idx][~ok].max():.3e} beyond max({tol:g}, 4*delta) and beyond {KAPPA_FACTOR:g} x kappa x unit at "
+                          f"{idx[~ok][:4]}: got {g[idx][~ok][:4]} want {w[idx][~ok][:4]}")
+        _record(what, "direct functions on the fuzz domain: beyond max(rtol, 4*delta), explained by the function's own amplification", int(idx.size),
+                max(3, 1e-3 * r.size), r.size)
+        assert idx.size <= max(3, 1e-3 * r.size), (what, int(idx.size))
     line = f"{what}: {r.size} points, worst {float(r[r <= tol].max()) if (r <= tol).any() else 0.0:.2e}, {relaxed} at 4*delta, inf-vs-huge {int(infmm.sum())}"
     CENSUS.append(line)
     return line

@@ -59,6 +59,15 @@ def test_direct_functions_on_the_fuzz_domain(ek, points, dev_points, func, keys,
     print(_fuzz.judge_direct(func, keys, kwargs, tag, d, got))
 
 
+@pytest.mark.parametrize("func,keys,kwargs", _fuzz.DIRECT_REST, ids=[f"{f}-{'-'.join(map(str, kw.values()))}" for f, _, kw in _fuzz.DIRECT_REST])
+def test_every_other_closed_form_case_on_the_fuzz_domain(ek, points, func, keys, kwargs):
+    """The rest of the 39 functions x variants (NumPy in, NumPy out)."""
+    tag, dtype, d = points
+    d = _fuzz.head(d)
+    got = getattr(ek.thermo, func)(*[d[k] for k in keys], **kwargs)
+    print(_fuzz.judge_direct(func, keys, kwargs, tag, d, got))
+
+
 @pytest.mark.parametrize("name", sorted(_fuzz.FUSED))
 def test_fused_pipelines_on_the_fuzz_domain(ek, points, dev_points, name):
     """BASELINE configs 3 and 5 far outside the benchmark distribution: every output held to the separate function's bar."""

@@ -46,6 +46,14 @@ def test_direct_functions_on_the_fuzz_domain(points, func, keys, kwargs):
     print(_fuzz.judge_direct(func, keys, kwargs, tag, d, got))
 
 
+@pytest.mark.parametrize("func,keys,kwargs", _fuzz.DIRECT_REST, ids=[f"{f}-{'-'.join(map(str, kw.values()))}" for f, _, kw in _fuzz.DIRECT_REST])
+def test_every_other_closed_form_case_on_the_fuzz_domain(points, func, keys, kwargs):
+    tag, dtype, d = points
+    d = _fuzz.head(d)
+    got = twin.by_reference_name(func, [d[k] for k in keys], dict(kwargs), dtype)
+    print(_fuzz.judge_direct(func, keys, kwargs, tag, d, got))
+
+
 @pytest.mark.parametrize("name", sorted(_fuzz.FUSED))
 def test_fused_pipelines_on_the_fuzz_domain(points, name):
     tag, dtype, d = points
