@@ -79,6 +79,38 @@ def test_fused_pipelines_on_the_fuzz_domain(ek, points, dev_points, name):
     print(_fuzz.judge_fused(name, tag, d, got))
 
 
+LEVELS = 64
+
+
+@pytest.mark.parametrize("method,t_method", [(m, tm) for m in _fuzz.METHODS for tm in _fuzz.T_METHODS] + [("ifs", "fused")])
+def test_level_vector_pressure_on_the_fuzz_domain(ek, points, method, t_method):
+    """The same draws of t and q as 64 levels x 16384 points with the pressure a LEVEL VECTOR (64 log-spaced levels, 1 Pa ...
+    1.26e5 Pa): the kernels that take p as a wave-uniform value per level (map_levels) on the wide domain -- the wet-bulb
+    by every method and the six-output pipeline, judged as the field-mode results are.  (N-d input to the bisection is a
+    superset of the reference, whose own bisection takes 1-d input only.)"""
+    tag, dtype, d = points
+    n = d["t"].size // LEVELS
+    t, q = d["t"].reshape(LEVELS, n), d["q"].reshape(LEVELS, n)
+    p = np.exp(np.linspace(np.log(1.0), np.log(1.26e5), LEVELS)).astype(dtype).reshape(LEVELS, 1)
+    flat = dict(t=t.ravel(), q=q.ravel(), p=np.broadcast_to(p, t.shape).ravel().copy())
+    dt_, dq, dp = ek.to_device(t), ek.to_device(q), ek.to_device(p)
+    try:
+        if t_method == "fused":
+            outs = ek.thermo.pipeline_full(dt_, dq, dp)
+            got = [o.to_host().ravel() for o in outs]
+            for o in outs:
+                o.free()
+            print(_fuzz.judge_fused("pipeline_full", tag, flat, got))
+        else:
+            out = ek.thermo.wet_bulb_temperature_from_specific_humidity(dt_, dq, dp, ept_method=method, t_method=t_method)
+            got = out.to_host().ravel()
+            out.free()
+            print(_fuzz.judge("wet_bulb_temperature_from_specific_humidity", ("t", "q", "p"), method, t_method, tag, flat, got))
+    finally:
+        for a in (dt_, dq, dp):
+            a.free()
+
+
 def _exact(on):
     from ekm_hip import _ffi
 
