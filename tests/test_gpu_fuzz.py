@@ -111,6 +111,39 @@ def test_level_vector_pressure_on_the_fuzz_domain(ek, points, method, t_method):
             a.free()
 
 
+@pytest.mark.parametrize("method,t_method", [("ifs", "bisect"), ("ifs", "newton"), ("bolton35", "bisect"), ("bolton39", "newton"), ("ifs", "fused")])
+def test_hybrid_level_pressure_on_the_fuzz_domain(ek, points, method, t_method):
+    """The same draws of t and q on the 137 IFS hybrid levels, the pressure formed INSIDE the kernels from a surface pressure
+    of 500 ... 1100 hPa (HybridPressure: bands of hybrid levels + the pure pressure levels as a level-vector launch)."""
+    from oracle import vertical_oracle as vo
+
+    tag, dtype, d = points
+    nlev = 137
+    n = (d["t"].size // nlev) // 8 * 8
+    t, q = d["t"][:nlev * n].reshape(nlev, n), d["q"][:nlev * n].reshape(nlev, n)
+    A, B = (x.astype(dtype) for x in ek.vertical.hybrid_level_parameters(nlev))
+    sp = np.random.default_rng(7).uniform(5e4, 1.1e5, n).astype(dtype)
+    p = np.stack([vo.pressure_on_hybrid_levels(A[k:k + 2], B[k:k + 2], sp)[0].reshape(n) for k in range(nlev)]).astype(dtype)
+    flat = dict(t=t.ravel(), q=q.ravel(), p=p.ravel())
+    dt_, dq, dsp = ek.to_device(t), ek.to_device(q), ek.to_device(sp)
+    hp = ek.HybridPressure(A, B, dsp)
+    try:
+        if t_method == "fused":
+            outs = ek.thermo.pipeline_full(dt_, dq, hp)
+            got = [o.to_host().ravel() for o in outs]
+            for o in outs:
+                o.free()
+            print(_fuzz.judge_fused("pipeline_full", tag, flat, got))
+        else:
+            out = ek.thermo.wet_bulb_temperature_from_specific_humidity(dt_, dq, hp, ept_method=method, t_method=t_method)
+            got = out.to_host().ravel()
+            out.free()
+            print(_fuzz.judge("wet_bulb_temperature_from_specific_humidity", ("t", "q", "p"), method, t_method, tag, flat, got))
+    finally:
+        for a in (dt_, dq, dsp):
+            a.free()
+
+
 def _exact(on):
     from ekm_hip import _ffi
 
