@@ -634,24 +634,32 @@ EKM_HD T qs_slope(T p, T es, T des, T epsv) {
 }
 
 // ---- dry thermodynamics ------------------------------------------------------
+// power with a NON-INTEGER exponent as the reference's namespace (libm) has it for a base of -inf: +inf for y > 0, +0 for
+// y < 0, as for +inf -- exp2(y*log2(-inf)) is NaN.  (A pressure of -0.0 makes p0/p = -inf; every other special base --
+// negative, zero of either sign, NaN -- comes out of exp2(y*log2(x)) as libm's pow has it.)
+template <class T>
+EKM_HD T m_pow_ni(T x, T y) {
+  return m_pow(x == T(-std::numeric_limits<double>::infinity()) ? -x : x, y);
+}
+
 template <class T>
 EKM_HD T theta(T t, T p) {  // thermo.py:801-829
-  return t * m_pow(m_div(T(k::p0), p), T(k::kappa));
+  return t * m_pow_ni(m_div(T(k::p0), p), T(k::kappa));
 }
 
 template <class T>
 EKM_HD T t_from_theta(T th, T p) {  // thermo.py:832-858
-  return th * m_pow(p * T(1.0 / k::p0), T(k::kappa));
+  return th * m_pow_ni(p * T(1.0 / k::p0), T(k::kappa));
 }
 
 template <class T>
 EKM_HD T p_on_dry_adiabat(T t, T t_def, T p_def) {  // thermo.py:861-889
-  return p_def * m_pow(m_div(t, t_def), T(1 / k::kappa));
+  return p_def * m_pow_ni(m_div(t, t_def), T(1 / k::kappa));
 }
 
 template <class T>
 EKM_HD T t_on_dry_adiabat(T p, T t_def, T p_def) {  // thermo.py:892-920
-  return t_def * m_pow(m_div(p, p_def), T(k::kappa));
+  return t_def * m_pow_ni(m_div(p, p_def), T(k::kappa));
 }
 
 template <class T>
@@ -663,7 +671,10 @@ template <int METHOD, class T>
 EKM_HD T lcl_t(T t, T td) {  // thermo.py:923-968
   if (METHOD == LCL_DAVIES)  // the two "- T0" of the reference's bracket folded into its constant: two fma
     return m_fnma(m_fnma(T(4.36e-4), t, m_fma(T(1.571e-3), td, T(0.212 - (1.571e-3 - 4.36e-4) * k::T0))), t - td, td);
-  return T(56.0) + m_rcp(m_fma(m_log(m_div(t, td)), T(1.0 / 800), m_rcp(td - T(56))));
+  // a saturated parcel (t == td): the reference's quotient is exactly 1 and its logarithm exactly 0; t*rcp(td) is one ulp off
+  // (finite and nonzero: inf/inf and 0/0 are NaN in the reference)
+  const T lr = (t - td == T(0) && t != T(0)) ? T(0) : m_log(m_div(t, td));
+  return T(56.0) + m_rcp(m_fma(lr, T(1.0 / 800), m_rcp(td - T(56))));
 }
 
 // exp2 whose result may be a denormal (v_exp_f32 flushes those to zero; the reference's exp / pow round them).  Needed
@@ -700,7 +711,7 @@ EKM_HD T ept(T t, T hum, T p) {
   }
   // bolton39, thermo.py:1268-1278
   const T e = e_from_w(w, p);
-  const T th = theta(t, p - e) * m_pow(m_div(t, tl), T(0.28) * w);
+  const T th = theta(t, p - e) * m_pow_ni(m_div(t, tl), T(0.28) * w);
   return th * m_exp((m_div(T(3036.0), tl) - T(1.78)) * w * (T(1) + T(0.448) * w));
 }
 
@@ -1103,6 +1114,9 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
     // reference where the logarithmic test reads +inf: with a NaN logarithm every test of such a point is NaN, i.e.
     // ambiguous, and every step takes the reference's own residual
     lq[j] = (METHOD != EPT_IFS && !(lte[j] < std::numeric_limits<float>::infinity())) ? nan_v<float>() : lte[j];
+    // a NEGATIVE te (a temperature handed over in Celsius) has no logarithm; the reference's residual te*2^g - t_m is
+    // negative at every node then, as for te = 0: the same walk (all the way down, 133.19 K), not NaN
+    if (METHOD == EPT_IFS && te[j] < 0.0f) lq[j] = -std::numeric_limits<float>::infinity();
     tfix[j] = 0.0f;
   }
   constexpr int REC = heap_rec<METHOD, float>();
@@ -1258,6 +1272,7 @@ EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (
     klf[j] = (float)kl[j];
     thr0[j] = float(1.5 * kHeapTau0) * pf[j];
     if (METHOD != EPT_IFS && !(ltef[j] < std::numeric_limits<float>::infinity())) ltef[j] = nan_v<float>();  // as in the fp32 walk
+    if (METHOD == EPT_IFS && te[j] < T(0.0)) ltef[j] = -std::numeric_limits<float>::infinity();              // likewise
     tfix[j] = T(0.0);
   }
   constexpr int REC = heap_rec<METHOD, double>();

@@ -354,3 +354,60 @@ def judge_fused(name, tag, d, outs):
             func, keys, kwargs = FUSED_AS[key]
             lines.append(judge_direct(func, keys, kwargs, tag, d, got))
     return "\n".join(f"{name}: {ln}" for ln in lines)
+
+
+# ---- special operands: NaN, infinities, zeros, negatives, the tiny and the huge, in every combination -----------------
+SPECIAL = [np.nan, np.inf, -np.inf, 0.0, -0.0, -1.0, 1e-30, 1e30]
+TYPICAL = dict(t=280.0, td=275.0, q=0.005, p=9e4, r=60.0, tc=7.0, w=0.005, e=800.0, es=1000.0, th=290.0, ept=310.0, t2=270.0, p2=7e4)
+
+
+def special_operands(keys, dtype):
+    import itertools
+
+    combos = np.array(list(itertools.product(*[SPECIAL + [TYPICAL[k]] for k in keys])), dtype=dtype)
+    return [combos[:, i].copy() for i in range(len(keys))]
+
+
+def judge_special(func, keys, kwargs, tag, ins, got):
+    """Every combination of SPECIAL values (and one typical value) per operand: the reference returns its NaN / inf in band
+    and so must the kernels -- same NaN positions, same infinities with their signs, finite results at the plain bar.
+    Not compared: the bisection with a pressure (or a humidity) that is infinite or 1e30 -- the reference's inf arithmetic
+    ends on some lattice point there (253.16 K for p = inf), the kernels return NaN."""
+    from oracle import thermo_oracle as orc
+
+    what = f"special operands {func}{sorted(kwargs.items())}[{tag}]"
+    with np.errstate(all="ignore"):
+        want = getattr(orc, func)(*[a.copy() for a in ins], **kwargs)
+    wl, gl = (want if isinstance(want, tuple) else (want,)), (got if isinstance(got, tuple) else (got,))
+    keep = np.ones(ins[0].shape, bool)
+    if kwargs.get("t_method") == "bisect":
+        for k, a in zip(keys, ins):
+            if k in ("p", "q", "w"):
+                keep &= np.abs(a) < 1e20
+    if func == "lcl" and kwargs.get("method") == "bolton":
+        # t = td = 1e-30 K: t_lcl = 56 + 1/(1/(td - 56)) cancels to +-4e-6 K by the rounding of the two reciprocals, and the
+        # LCL pressure p*(t_lcl/t)^3.5 formed from it is inf or NaN by that sign
+        keep &= ~((ins[0] == ins[0].dtype.type(1e-30)) & (ins[1] == ins[1].dtype.type(1e-30)))
+    from oracle import conditioning
+
+    tol = 1e-4 if tag == "f32" else F64_ASSERT
+    ins64 = [a.astype(np.float64)[keep] for a in ins]
+    for k, (w, g) in enumerate(zip(wl, gl)):
+        w, g = np.asarray(w, dtype=np.float64)[keep], np.asarray(g, dtype=np.float64)[keep]
+        assert np.array_equal(np.isnan(w), np.isnan(g)), (what, k, "NaN pattern", np.flatnonzero(np.isnan(w) != np.isnan(g))[:4])
+        inf = np.isinf(w)
+        assert np.array_equal(inf, np.isinf(g)) and np.array_equal(np.sign(w[inf]), np.sign(g[inf])), (what, k, "infinities")
+        fin = np.isfinite(w)
+        # finite results: the plain bar, relative to max(|result|, 1) (t_lcl(1e-30, 1e-30) is 56 - 56.000004: a zero that is
+        # the rounding of its terms) ...
+        with np.errstate(all="ignore"):
+            r = np.abs(g - w) / np.maximum(np.abs(w), 1.0)
+        r = np.where(fin & (w != g), r, 0.0)
+        idx = np.flatnonzero(r > tol)
+        if idx.size:  # ... unless the function itself amplifies a 1e-6 change of an operand beyond all bounds there (t_lcl(1e30,
+            # 1e30) = 56 + 1/(1e-30 + log(t/td)/800): the reference's exact t/td = 1 against a quotient one ulp off)
+            f64 = (lambda *x: getattr(orc, func)(*x, **kwargs)[k]) if isinstance(want, tuple) else (lambda *x: getattr(orc, func)(*x, **kwargs))
+            finite_k, edge = conditioning.misses_explained(f64, [a[idx] for a in ins64], g[idx], w[idx], tol, unit=UNIT[tag], factor=KAPPA_FACTOR)
+            ok = finite_k | edge
+            assert ok.all(), (what, k, float(r[idx][~ok].max()), idx[~ok][:4], [tuple(a[i] for a in ins64) for i in idx[~ok][:4]], g[idx][~ok][:4], w[idx][~ok][:4])
+    return f"{what}: {int(keep.sum())} combinations"

@@ -221,3 +221,13 @@ def test_bolton39_with_an_infinite_theta_e(ek, dtype, t, td, p, expect):
     got = ek.thermo.wet_bulb_temperature_from_dewpoint(np.array([t], dtype), np.array([td], dtype), np.array([p], dtype),
                                                        ept_method="bolton39", t_method="bisect")
     assert got.dtype == dtype and abs(float(got[0]) - expect) < 1e-4, got
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("func,keys,kwargs", _fuzz._case_table(), ids=[f"{f}-{'-'.join(map(str, kw.values()))}" for f, _, kw in _fuzz._case_table()])
+def test_special_operands_in_every_combination(ek, tag, func, keys, kwargs):
+    """NaN, infinities, zeros, negatives, 1e-30 and 1e30 in every combination, all 39 functions x variants (NumPy in / out)."""
+    dtype = np.float32 if tag == "f32" else np.float64
+    ins = _fuzz.special_operands(keys, dtype)
+    got = getattr(ek.thermo, func)(*ins, **kwargs)
+    print(_fuzz.judge_special(func, keys, kwargs, tag, ins, got))

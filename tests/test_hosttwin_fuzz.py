@@ -114,3 +114,12 @@ def test_bolton39_with_an_infinite_theta_e(dtype, t, td, p, expect):
     got = twin.by_reference_name("wet_bulb_temperature_from_dewpoint", [np.array([t]), np.array([td]), np.array([p])],
                                  dict(ept_method="bolton39", t_method="bisect"), dtype)
     assert abs(float(got[0]) - expect) < 1e-4, got
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("func,keys,kwargs", _fuzz._case_table(), ids=[f"{f}-{'-'.join(map(str, kw.values()))}" for f, _, kw in _fuzz._case_table()])
+def test_special_operands_in_every_combination(tag, func, keys, kwargs):
+    dtype = np.float32 if tag == "f32" else np.float64
+    ins = _fuzz.special_operands(keys, dtype)
+    got = twin.by_reference_name(func, ins, dict(kwargs), dtype)
+    print(_fuzz.judge_special(func, keys, kwargs, tag, ins, got))
