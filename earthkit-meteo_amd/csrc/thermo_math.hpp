@@ -1056,14 +1056,15 @@ EKM_HD float bisect_fast_test(float es, float a, float u, float p, float kl, flo
   } else {
     w = p - es;
     const float ees = float(k::eps) * es;
-    scale = (a * ees) * m_fma(0.448f, ees, w);
+    const float aees = a * ees;
+    scale = aees * m_fma(0.448f, ees, w);
     const float v2 = w * w;
     const float X = m_fnma(float(k::kappa), m_log2(w * float(1.0 / k::p0)), u);
     D = m_fms(v2, X, scale);
     thr0 = float(2.0 * kHeapTau0) * v2;  // the band in units of v^2 here (log2 of a small v adds its own rounding)
     // the fp64 walk tests on p and es ROUNDED to float: w = p - es is off by up to 1.2e-7*p, which where it cancels is
     // more than the band above knows of -- dD = dw*(2*w*|X| + kappa/ln2*w + |a|*eps*es)
-    if (F64) thr0 = m_fma(1.5e-7f * p, m_fma(w, m_fma(2.0f, __builtin_fabsf(X), 0.5f), __builtin_fabsf(a) * ees), thr0);
+    if (F64) thr0 = m_fma(1.5e-7f * p, m_fma(w, m_fma(2.0f, __builtin_fabsf(X), 0.5f), __builtin_fabsf(aees)), thr0);
   }
   amb = !(__builtin_fabsf(D) > m_fma(__builtin_fabsf(scale), float(METHOD == EPT_IFS ? kHeapTau1 : 2.0 * kHeapTau1), thr0));  // NaN: ambiguous
   if (METHOD == EPT_BOLTON35 && WS) amb = amb || big_ws;

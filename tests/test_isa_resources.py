@@ -76,8 +76,9 @@ TREE = re.compile(r"(7OpTOnMa|15OpWetBulbFromTd|14OpWetBulbFromQ|12OpWbptFromTd|
 def test_no_kernel_of_the_built_library_runs_out_of_registers(built_kernels):
     """Scratch memory = registers spilled: nowhere, except 12 B per lane in full-field tree-walk kernels from three inputs
     (bolton35; the fp32 IFS walk at its 64-register cap), spilled once at kernel entry (the lane's first element index,
-    reloaded for the ragged tail), outside the tile loop."""
-    allowed = re.compile(r"map_fieldsINS_1[1245]Op(WetBulb|Wbpt)From(Q|Td)ILi[01]ELi0EEEfLi1E")
+    reloaded for the ragged tail), outside the tile loop; and 12 B in ONE fp64 kernel at its 128-register cap (the bolton39
+    walk from (t, q) on hybrid levels: two 8-byte values parked around the walk, four scratch instructions in 15,900)."""
+    allowed = re.compile(r"map_fieldsINS_1[1245]Op(WetBulb|Wbpt)From(Q|Td)ILi[01]ELi0EEEfLi1E|map_levelsINS_14OpWetBulbFromQILi2ELi0EEEdLi2ELb0E")
     bad = {k: v for k, v in built_kernels.items() if v["scratch"] > (12 if allowed.search(k) else 0)}
     assert not bad, bad
 
