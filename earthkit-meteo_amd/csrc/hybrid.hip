@@ -37,7 +37,9 @@ __device__ __forceinline__ void layer_delta_alpha(float p_hi, float p_lo, float&
   q = __builtin_fmaf(q, z, 1.0f / 3.0f);
   q = __builtin_fmaf(q, z, 1.0f);
   d = 2.0f * s * q;
-  if (!(s < 0.25f)) d = log(p_lo / p_hi);  // thick layers (and inf / NaN / negative pressure): libm
+  // thick layers, and a pressure that does not grow downwards or is not a positive number (a surface pressure of zero,
+  // a negative one, inf, NaN: s <= -0.25, |s| > 1 for opposite signs, NaN): libm, as the reference has it
+  if (!(__builtin_fabsf(s) < 0.25f)) d = log(p_lo / p_hi);
   a = 1.0f - p_hi * __builtin_amdgcn_rcpf(dif) * d;
 }
 

@@ -342,3 +342,19 @@ def test_row_ordered_and_column_kernels_agree_bit_for_bit(ek, dt):
                 assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), (npts, levels, name)
     finally:
         _ffi.check(lib.ekm_set_tuning_param(b"hybrid_rows", 1))
+
+
+def test_special_operands_through_the_hybrid_level_functions(ek):
+    """NaN, infinities, zeros, negatives, 1e-30 and 1e30 as surface pressure, as t / q at one level and as surface
+    geopotential, in every combination (6561 columns x 137 levels, both dtypes), through pressure_on_hybrid_levels (every
+    output, both alpha_top), the geopotential chain (thickness, geopotential, the four heights) and w_from_omega: same NaN /
+    inf pattern as the oracle, finite values at the bar (fp32: max(1e-4, 4 x the reference's own fp32-vs-fp64 distance --
+    its alpha = 1 - p/dp*log(..) cancels in fp32)).  tools/special_probe_vertical.py prints what differs."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "special_probe_vertical.py")
+    spec = importlib.util.spec_from_file_location("special_probe_vertical", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main() == 0
