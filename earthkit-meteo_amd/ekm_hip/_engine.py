@@ -225,7 +225,51 @@ def run(name, args, ints=(), eps=None, dtype=None):
     args, foreign = _adopt_foreign(args)
     if foreign is not None:
         return _hand_back(_run(name, args, ints, eps, dtype), foreign)
-    return _run(name, args, ints, eps, dtype)
+    outs = _run(name, args, ints, eps, dtype)
+    if dtype is None:
+        outs = _as_the_reference_types_them(name, ints, args, outs)
+    return outs
+
+
+# ---- the reference's own result types on the NumPy path ---------------------------------------------------------------------
+# Plain promotion with weak Python scalars is what the reference does where a function uses an operand as it comes; where
+# it passes the operand through `xp.asarray` first the scalar is a float64 array and the result float64
+# (potential_temperature(280.0, p_float32)); theta_w "direct" is float64 even from float32 arrays; temperature_on_moist_
+# adiabat takes its type from theta_e alone; lcl's t_lcl depends on (t, td) only -- in type AND shape.  The deviations from
+# plain promotion were recorded from the reference (tests/golden/gen_dtype_rules.py -> _dtype_rules.RULES, data only) and
+# are applied to what a NumPy call returns; the arithmetic keeps the promotion's type (a float64 result of float32
+# arithmetic is what the reference has there, too).  DeviceArrays and other libraries' arrays keep their own types.
+def _kind_of(a):
+    if type(a) in (float, int, bool):
+        return "s"
+    if isinstance(a, (np.ndarray, np.generic, list, tuple)):
+        return "f" if np.asarray(a).dtype == _F32 else "d"
+    return None
+
+
+def _as_the_reference_types_them(name, ints, args, outs):
+    from ._dtype_rules import RULES
+
+    lcl = name == "lcl"
+    rules = RULES.get((name, tuple(int(i) for i in ints)))
+    if rules is None and not lcl:
+        return outs
+    kinds = [_kind_of(a) for a in args]
+    if None in kinds or not all(isinstance(o, (np.ndarray, np.generic)) for o in outs):
+        return outs
+    outs = list(outs)
+    chars = (rules or {}).get("".join(kinds))
+    if chars is not None:
+        outs = [np.asarray(o).astype(_F32 if c == "f" else _F64, copy=False) if np.ndim(o) else (np.float32 if c == "f" else np.float64)(o)
+                for o, c in zip(outs, chars)]
+    if lcl and np.ndim(outs[0]):  # t_lcl has the shape of broadcast(t, td); the values do not vary along p's own axes
+        full = np.shape(outs[0])
+        want = np.broadcast_shapes(np.shape(args[0]), np.shape(args[1]))
+        if tuple(want) != tuple(full):
+            padded = (1,) * (len(full) - len(want)) + tuple(want)
+            t_lcl = np.asarray(outs[0])[tuple(slice(None) if w == f else slice(0, 1) for w, f in zip(padded, full))].reshape(want)
+            outs[0] = t_lcl.copy() if t_lcl.ndim else t_lcl.dtype.type(t_lcl)
+    return tuple(outs)
 
 
 # ---- Python scalars beside DeviceArrays ---------------------------------------------------------------------------------

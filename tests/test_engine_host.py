@@ -197,3 +197,40 @@ def test_array_namespaces_as_in_the_reference():
     assert ekm_hip.vertical.array.hybrid_level_parameters is ekm_hip.vertical.hybrid_level_parameters
     assert ekm_hip.vertical.array.height_on_hybrid_levels is ekm_hip.vertical.height_on_hybrid_levels
     assert ekm_hip.wind.array.w_from_omega is ekm_hip.wind.w_from_omega
+
+
+def test_results_are_typed_as_the_reference_types_them():
+    """ekm_hip/_dtype_rules.py (recorded from the reference by tests/golden/gen_dtype_rules.py) applied to what a NumPy call
+    returns: a Python scalar is float64 where the reference passes that operand through asarray, weak elsewhere; theta_w
+    "direct" is float64 from float32 arrays; temperature_on_moist_adiabat follows theta_e; lcl's t_lcl follows (t, td) in type
+    and shape.  No GPU: the rule is applied to stand-in results."""
+    import numpy as np
+
+    from ekm_hip import _engine as e
+    from ekm_hip._dtype_rules import RULES
+    from ekm_hip.thermo import EPT_METHOD, LCL_METHOD, T_METHOD
+
+    f = np.ones((3, 2), np.float32)
+    d = np.ones((3, 2), np.float64)
+    typed = lambda name, ints, args, outs: [(np.shape(o), np.asarray(o).dtype.char) for o in e._as_the_reference_types_them(name, ints, args, outs)]  # noqa: E731
+    assert typed("potential_temperature", (), (280.0, f), (f.copy(),)) == [((3, 2), "d")]
+    assert typed("potential_temperature", (), (f, f), (f.copy(),)) == [((3, 2), "f")]
+    assert typed("relative_humidity_from_specific_humidity", (), (f, f, 9e4), (f.copy(),)) == [((3, 2), "f")]
+    assert typed("relative_humidity_from_specific_humidity", (), (280.0, f, f), (f.copy(),)) == [((3, 2), "d")]
+    direct = (EPT_METHOD["ifs"], T_METHOD["direct"])
+    assert typed("wet_bulb_potential_temperature_from_specific_humidity", direct, (f, f, f), (f.copy(),)) == [((3, 2), "d")]
+    bis = (EPT_METHOD["ifs"], T_METHOD["bisect"])
+    assert typed("temperature_on_moist_adiabat", bis, (f, d), (d.copy(),)) == [((3, 2), "f")]
+    lcl = (LCL_METHOD["davies"],)
+    assert typed("lcl", lcl, (f[:, :1], f[:1, :1], d), (d.copy(), d.copy())) == [((3, 1), "f"), ((3, 2), "d")]
+    assert typed("lcl", lcl, (f, f, d), (d.copy(), d.copy())) == [((3, 2), "f"), ((3, 2), "d")]
+    assert typed("lcl", lcl, (f, f, f), (f.copy(), f.copy())) == [((3, 2), "f"), ((3, 2), "f")]
+    # a DeviceArray-like operand (anything that is not NumPy / a Python scalar) leaves the results alone
+    assert typed("potential_temperature", (), (object(), 280.0), (f.copy(),)) == [((3, 2), "f")]
+    # the table is data: entry points the library has, kinds of the right length, float32 / float64 only
+    from ekm_hip._optable import OPS
+    for (name, ints), rules in RULES.items():
+        nin, nout = len(OPS[name][0]), len(OPS[name][1])
+        assert len(ints) == len(OPS[name][2])
+        for kinds, chars in rules.items():
+            assert len(kinds) == nin and set(kinds) <= set("fds") and len(chars) == nout and set(chars) <= set("fd")

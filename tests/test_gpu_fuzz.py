@@ -231,3 +231,22 @@ def test_special_operands_in_every_combination(ek, tag, func, keys, kwargs):
     ins = _fuzz.special_operands(keys, dtype)
     got = getattr(ek.thermo, func)(*ins, **kwargs)
     print(_fuzz.judge_special(func, keys, kwargs, tag, ins, got))
+
+
+def test_random_shapes_dtypes_and_layouts_through_the_numpy_path(ek):
+    """tools/shape_fuzz.py: 300 random calls -- broadcast patterns, float32 / float64 / Python-scalar / list / 0-d operands,
+    Fortran-ordered, strided and reversed views -- against the oracle, which agrees with the reference itself on all of them
+    (`--reference` in the build container: 0 differences): result shape, result dtype (ekm_hip/_dtype_rules.py), values."""
+    import importlib.util
+    import os
+    import sys
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "shape_fuzz.py")
+    spec = importlib.util.spec_from_file_location("shape_fuzz", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv, sys.argv = sys.argv, ["shape_fuzz.py", "--trials", "300"]
+    try:
+        assert mod.main() == 0
+    finally:
+        sys.argv = argv

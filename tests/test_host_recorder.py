@@ -275,10 +275,14 @@ def test_a_tiny_numpy_call_is_a_launch_and_a_wait(rec, monkeypatch):
     assert all(o == ops[0] for o in ops) and [m for _, m, _, _ in ops[0]] == [_ffi.FIELD, _ffi.FIELD]
     blk = _engine._tiny_tls.blocks[0]
     assert np.frombuffer(blk.buf, np.float64, 2, ops[0][0][0] - blk.ptr).tolist() == t.tolist()   # the operands sit in the block
-    # scalars in, a NumPy scalar out; float32 stays float32; float16 computes in float32 and comes back as float16
+    # scalars in, a NumPy scalar out; a Python scalar beside float32 arrays is weak where the reference uses it as it comes
+    # (the result stays float32) and float64 where the reference passes it through asarray first (potential_temperature:
+    # recorded from the reference, ekm_hip/_dtype_rules.py); float16 computes in float32 and comes back as float16
     s = ekm_hip.thermo.potential_temperature(264.12, 85000.0)
     assert isinstance(s, np.float64)
-    assert ekm_hip.thermo.potential_temperature(t.astype(np.float32), 85000.0).dtype == np.float32
+    t32 = t.astype(np.float32)
+    assert ekm_hip.thermo.relative_humidity_from_specific_humidity(t32, np.full(2, 0.004, np.float32), 85000.0).dtype == np.float32
+    assert ekm_hip.thermo.potential_temperature(t32, 85000.0).dtype == np.float64
     assert ekm_hip.thermo.potential_temperature(t.astype(np.float16), (p * 0.5).astype(np.float16)).dtype == np.float16
     # a level vector against a small field keeps its broadcast class; lists and big arrays go the general way
     rec.calls.clear()
