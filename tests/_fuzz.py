@@ -295,12 +295,13 @@ def _judge_direct(what, tag, in_dtype, got, want, ref64, f64, ins64):
     from oracle import conditioning
 
     got, want = np.asarray(got), np.asarray(want)
-    # (theta_w "direct" in fp32: the reference's result comes back as float64 through the float64 coefficient lists of its
-    # namespace's polyval -- a property of that third-party helper; the kernels keep the input dtype, values are compared)
-    assert got.dtype == in_dtype and got.shape == want.shape, (what, got.dtype, got.shape)
-    g, w = got.astype(np.float64), want.astype(got.dtype).astype(np.float64)
+    # (theta_w "direct" from float32: the reference's result is float64 -- the float64 coefficient lists of its polyval --, and so
+    # is a NumPy call's here (ekm_hip/_dtype_rules.py); a DeviceArray keeps the dtype of its operands; values are compared)
+    assert got.dtype in (in_dtype, want.dtype) and got.shape == want.shape, (what, got.dtype, got.shape)
+    # (compared in the dtype of the ARITHMETIC: a float64 result typed from float32 arithmetic overflows where float32 does)
+    g, w = got.astype(in_dtype).astype(np.float64), want.astype(in_dtype).astype(np.float64)
     assert np.array_equal(np.isnan(g), np.isnan(w)), f"{what}: NaN pattern differs at {np.flatnonzero(np.isnan(g) != np.isnan(w))[:4]}"
-    big = float(np.finfo(got.dtype).max) / 1e2
+    big = float(np.finfo(in_dtype).max) / 1e2
     infmm = np.isinf(g) != np.isinf(w)
     with np.errstate(all="ignore"):
         near_overflow = np.where(np.isinf(g), np.abs(w), np.abs(g)) > big

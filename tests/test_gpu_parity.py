@@ -37,8 +37,9 @@ def test_golden_vectors(ek, case):
 
     cid = case["id"].split(".")
     for i, (o, g) in enumerate(zip(_outs(out), case_outputs(case))):
-        want_dtype = np.float32 if case["dtype"] == "f32" else np.float64
-        assert o.dtype == want_dtype, (case["id"], o.dtype)  # dtype-preserving (fp32 in -> fp32 out)
+        # the dtype the REFERENCE returned (fp32 in -> fp32 out, except theta_w "direct", which is float64 from float32
+        # arrays in the reference: the float64 coefficient lists of its polyval; ekm_hip/_dtype_rules.py)
+        assert o.dtype == g.dtype, (case["id"], o.dtype, g.dtype)
         both = [golden()[".".join([cid[0], tag] + cid[2:]) + f".out{i}"] for tag in ("f32", "f64")]
         unstable = ref64 = noise_t = None
         if bisect:
@@ -459,8 +460,9 @@ def test_multi_gpu_sharding_in_process(ek, orc, slab):
         lev = ek.thermo.potential_temperature(t, p[:, :1].copy())          # [16, 1] level vector: sliced per shard
         sc = ek.thermo.dewpoint_from_specific_humidity(q, np.float32(85000.0))  # scalar: passed whole
         few = ek.thermo.potential_temperature(t[:2], p[:2])                 # fewer rows than devices: single path
-        weak = ek.thermo.potential_temperature(t, 85000.0)                  # Python scalar stays weak: fp32 result
-    assert weak.dtype == np.float32 and weak.shape == t.shape
+        weak = ek.thermo.dewpoint_from_specific_humidity(q, 85000.0)        # Python scalar stays weak here: fp32 result
+        strong = ek.thermo.potential_temperature(t, 85000.0)                # ... and is float64 here, as in the reference
+    assert weak.dtype == np.float32 and weak.shape == t.shape and strong.dtype == np.float64 and strong.shape == t.shape
     for a, b in zip(single, multi):
         assert b.shape == t.shape and b.dtype == np.float32 and np.array_equal(a, b, equal_nan=True)
     assert_parity(lev, orc.potential_temperature(t, p[:, :1]), "f32", "sharded level vector")
