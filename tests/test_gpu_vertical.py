@@ -358,3 +358,22 @@ def test_special_operands_through_the_hybrid_level_functions(ek):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main() == 0
+
+
+def test_random_shapes_levels_outputs_and_axes_through_the_hybrid_level_functions(ek):
+    """tools/shape_fuzz_vertical.py: 200 random calls -- surface-pressure shapes of 0 ... 3 dimensions, both dtypes, L91 / L137,
+    level subsets, output selections, alpha_top, the vertical axis moved, Fortran-ordered views -- against the oracle, which
+    agrees with the reference itself on every such call (`--reference` in the build container)."""
+    import importlib.util
+    import os
+    import sys
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "shape_fuzz_vertical.py")
+    spec = importlib.util.spec_from_file_location("shape_fuzz_vertical", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv, sys.argv = sys.argv, ["shape_fuzz_vertical.py", "--trials", "200"]
+    try:
+        assert mod.main() == 0
+    finally:
+        sys.argv = argv
