@@ -245,8 +245,11 @@ def test_random_shapes_dtypes_and_layouts_through_the_numpy_path(ek):
     spec = importlib.util.spec_from_file_location("shape_fuzz", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    argv, sys.argv = sys.argv, ["shape_fuzz.py", "--trials", "300"]
+    argv = sys.argv
     try:
+        sys.argv = ["shape_fuzz.py", "--trials", "300"]
+        assert mod.main() == 0
+        sys.argv = ["shape_fuzz.py", "--trials", "300", "--device"]  # the same calls with DeviceArray operands: shapes and values
         assert mod.main() == 0
     finally:
         sys.argv = argv

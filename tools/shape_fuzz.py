@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--trials", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--reference", action="store_true", help="run the reference itself in place of the library (build container)")
+    ap.add_argument("--device", action="store_true", help="hand the array operands over as DeviceArrays (results come back as "
+                    "DeviceArrays in the promotion's dtype: shapes and values are compared, not the reference's result typing)")
     a = ap.parse_args()
     from oracle import thermo_oracle as orc
 
@@ -85,7 +87,14 @@ def main():
         except Exception:  # the reference raises (a list times a float, a mask index into a 0-d array): the library accepting
             continue       # such a call is a superset, like N-d input to the bisection; nothing to compare
         try:
-            got = getattr(ek.thermo, func)(*ops, **kw)
+            if a.device:
+                dops = [ek.to_device(np.ascontiguousarray(o)) if isinstance(o, np.ndarray) and o.ndim else o for o in ops]
+                if not any(isinstance(o, ek.DeviceArray) for o in dops):
+                    continue
+                got = getattr(ek.thermo, func)(*dops, **kw)
+                got = tuple(g.to_host() for g in got) if isinstance(got, tuple) else got.to_host()
+            else:
+                got = getattr(ek.thermo, func)(*ops, **kw)
         except Exception as ex:
             print(f"trial {trial} {func} {kinds} shapes {[np.shape(o) for o in ops]}: library raises {type(ex).__name__}: {str(ex)[:120]}")
             bad += 1
@@ -98,6 +107,10 @@ def main():
             # a float32 t carries 2.5e-6), the library computes everything in float64 -- the comparison is float32-grade there
             mixed = any(k.startswith(("f32", "zerod")) for k in kinds)
             tol = 1e-4 if w.dtype == np.float32 else (1e-5 if mixed else 1e-7)
+            if a.device:  # the promotion's dtype (float32 unless an operand is float64): compare there
+                w = w.astype(g.dtype)
+                if func == "lcl" and k == 0 and w.shape != g.shape:
+                    w = np.broadcast_to(w, g.shape)  # (a DeviceArray result has the full broadcast shape)
             ok = w.shape == g.shape and w.dtype == g.dtype
             if ok:
                 both = np.isfinite(w) & np.isfinite(g)
