@@ -217,6 +217,18 @@ def _chain(t, q, zs, A, B, sp, alpha_top, mode, vertical_axis):
     dtype = _F32 if np.result_type(*parts, 0.0) == _F32 else _F64
     out_parts = [host["t"].dtype, host["q"].dtype] + ([host["zs"].dtype] if zs is not None and mode not in (0, 5) else [])
     out_dtype = np.result_type(*out_parts, np.float32 if all(p == _F32 for p in out_parts) else 0.0)
+    if not on_device and host["t"].ndim >= 1:
+        # NumPy input broadcasts as it does in the reference (t of [levels, 1] against q and sp of [.., n]): the level count is
+        # t's (vertical.py:1191-1203), everything is brought to [levels, *columns] on the host
+        try:
+            full = np.broadcast_shapes(host["t"].shape, host["q"].shape, (host["t"].shape[0],) + tuple(host["sp"].shape))
+            if full[0] == host["t"].shape[0] and (host["zs"] is None or np.broadcast_shapes(full[1:], host["zs"].shape) == full[1:]):
+                host["t"], host["q"] = np.broadcast_to(host["t"], full), np.broadcast_to(host["q"], full)
+                host["sp"] = np.broadcast_to(host["sp"], full[1:])
+                if host["zs"] is not None:
+                    host["zs"] = np.broadcast_to(host["zs"], full[1:])
+        except ValueError:
+            pass  # not broadcastable: the shape error below
     shape = tuple(host["t"].shape)
     if tuple(host["q"].shape) != shape or shape[1:] != tuple(host["sp"].shape):
         raise ValueError(f"t {shape}, q {tuple(host['q'].shape)} must be [levels, *sp.shape] with sp {tuple(host['sp'].shape)}")
