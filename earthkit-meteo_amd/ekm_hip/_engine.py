@@ -240,7 +240,10 @@ def run(name, args, ints=(), eps=None, dtype=None):
 # are applied to what a NumPy call returns; the arithmetic keeps the promotion's type (a float64 result of float32
 # arithmetic is what the reference has there, too).  DeviceArrays and other libraries' arrays keep their own types.
 def _kind_of(a):
-    if type(a) in (float, int, bool):
+    ta = type(a)
+    if ta is np.ndarray:
+        return "f" if a.dtype == _F32 else "d"
+    if ta in (float, int, bool):
         return "s"
     if isinstance(a, (np.ndarray, np.generic, list, tuple)):
         return "f" if np.asarray(a).dtype == _F32 else "d"
