@@ -225,6 +225,9 @@ def test_results_are_typed_as_the_reference_types_them():
     assert typed("lcl", lcl, (f[:, :1], f[:1, :1], d), (d.copy(), d.copy())) == [((3, 1), "f"), ((3, 2), "d")]
     assert typed("lcl", lcl, (f, f, d), (d.copy(), d.copy())) == [((3, 2), "f"), ((3, 2), "d")]
     assert typed("lcl", lcl, (f, f, f), (f.copy(), f.copy())) == [((3, 2), "f"), ((3, 2), "f")]
+    # the reference's bisection runs on atleast_1d(theta_e): 0-d operands come back with shape (1,); Newton's stay 0-d
+    assert typed("temperature_on_moist_adiabat", bis, (320.0, 9e4), (np.float64(290.0),)) == [((1,), "d")]
+    assert typed("temperature_on_moist_adiabat", (EPT_METHOD["ifs"], T_METHOD["newton"]), (320.0, 9e4), (np.float64(290.0),)) == [((), "d")]
     # a DeviceArray-like operand (anything that is not NumPy / a Python scalar) leaves the results alone
     assert typed("potential_temperature", (), (object(), 280.0), (f.copy(),)) == [((3, 2), "f")]
     # the table is data: entry points the library has, kinds of the right length, float32 / float64 only

@@ -16,8 +16,23 @@ FUNCS = [("potential_temperature", ("t", "p"), {}), ("relative_humidity_from_spe
          ("saturation_vapour_pressure", ("t",), {}), ("dewpoint_from_specific_humidity", ("q", "p"), {}),
          ("ept_from_specific_humidity", ("t", "q", "p"), {"method": "ifs"}),
          ("wet_bulb_temperature_from_specific_humidity", ("t", "q", "p"), {"ept_method": "ifs", "t_method": "newton"}),
-         ("lcl", ("t", "td", "p"), {"method": "davies"}), ("virtual_temperature", ("t", "q"), {})]
-RANGE = dict(t=(230.0, 310.0), td=(225.0, 300.0), q=(1e-5, 0.02), p=(2e4, 1.05e5))
+         ("lcl", ("t", "td", "p"), {"method": "davies"}), ("virtual_temperature", ("t", "q"), {}),
+         ("wet_bulb_temperature_from_specific_humidity", ("t", "q", "p"), {"ept_method": "ifs", "t_method": "bisect"}),
+         ("temperature_on_moist_adiabat", ("ept", "p"), {"ept_method": "bolton35", "t_method": "bisect"}),
+         ("wet_bulb_potential_temperature_from_dewpoint", ("t", "td", "p"), {"ept_method": "bolton39", "t_method": "direct"}),
+         ("saturation_specific_humidity_slope", ("t", "p"), {"phase": "ice"}),
+         ("temperature_on_dry_adiabat", ("p", "t", "p"), {})]
+RANGE = dict(t=(230.0, 310.0), td=(225.0, 300.0), q=(1e-5, 0.02), p=(2e4, 1.05e5), ept=(280.0, 360.0), r=(5.0, 100.0), tc=(-40.0, 35.0),
+             w=(1e-5, 0.02), e=(10.0, 3000.0), es=(10.0, 4000.0), th=(250.0, 330.0), t2=(220.0, 300.0), p2=(1.5e4, 9e4))
+
+
+def _all_cases():
+    import _fuzz
+
+    return [(f, tuple(k), kw) for f, k, kw in _fuzz._case_table()]
+
+
+ALL = _all_cases()
 
 
 def operand(rng, key, full):
@@ -58,6 +73,7 @@ def main():
     ap.add_argument("--trials", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--reference", action="store_true", help="run the reference itself in place of the library (build container)")
+    ap.add_argument("--all", action="store_true", help="draw from all 94 function x variant cases (tests/golden/_case_table.py)")
     ap.add_argument("--device", action="store_true", help="hand the array operands over as DeviceArrays (results come back as "
                     "DeviceArrays in the promotion's dtype: shapes and values are compared, not the reference's result typing)")
     a = ap.parse_args()
@@ -78,7 +94,7 @@ def main():
     rng = np.random.default_rng(a.seed)
     bad = 0
     for trial in range(a.trials):
-        func, keys, kw = FUNCS[rng.integers(len(FUNCS))]
+        func, keys, kw = (ALL if a.all else FUNCS)[rng.integers(len(ALL if a.all else FUNCS))]
         nd = int(rng.integers(1, 4))
         full = [int(rng.choice([1, 2, 3, 5, 8, 17, 64, 130])) for _ in range(nd)]
         ops, kinds = zip(*[operand(rng, k, full) for k in keys])
