@@ -253,3 +253,17 @@ def test_random_shapes_dtypes_and_layouts_through_the_numpy_path(ek):
         assert mod.main() == 0
     finally:
         sys.argv = argv
+
+
+@pytest.mark.parametrize("mode", [["--stream"], ["--multi", "3", "--seed", "2"]], ids=["streamed", "sharded"])
+def test_random_shapes_through_the_streamed_and_the_sharded_path(mode):
+    """tools/shape_fuzz.py with every NumPy call forced through the streamed path (slices of the leading axis, uploader and
+    downloader threads, a 24-MiB budget) resp. inside multi_gpu([0, 0, 0]) -- in a child process: it lowers module-level
+    thresholds of the engine."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "shape_fuzz.py"), "--trials", "300"] + mode, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "300 trials, 0 differences" in r.stdout, (r.stdout[-800:], r.stderr[-800:])

@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--reference", action="store_true", help="run the reference itself in place of the library (build container)")
     ap.add_argument("--all", action="store_true", help="draw from all 94 function x variant cases (tests/golden/_case_table.py)")
+    ap.add_argument("--stream", action="store_true", help="send every NumPy call through the streamed path (slices of the leading "
+                    "axis, uploader / downloader threads) by setting its threshold to one byte, with a small slice budget")
+    ap.add_argument("--multi", type=int, default=0, help="inside ekm_hip.multi_gpu([0] * N): the sharded path on one GPU")
     ap.add_argument("--device", action="store_true", help="hand the array operands over as DeviceArrays (results come back as "
                     "DeviceArrays in the promotion's dtype: shapes and values are compared, not the reference's result typing)")
     a = ap.parse_args()
@@ -92,6 +95,25 @@ def main():
 
     np.seterr(all="ignore")
     rng = np.random.default_rng(a.seed)
+    bad = 0
+    import contextlib
+
+    ctx = contextlib.nullcontext()
+    if not a.reference and (a.stream or a.multi):
+        from ekm_hip import _engine
+
+        _engine._STREAM_BYTES, _engine._TINY_BYTES = 1, 0
+        if a.stream:
+            os.environ["EKM_STREAM_BUDGET_BYTES"] = os.environ.get("EKM_STREAM_BUDGET_BYTES", str(24 << 20))
+        if a.multi:
+            ctx = ek.multi_gpu([0] * a.multi)
+    with ctx:
+        bad = _trials(a, rng, ek, orc)
+    print(f"shape fuzz: {a.trials} trials, {bad} differences")
+    return bad
+
+
+def _trials(a, rng, ek, orc):
     bad = 0
     for trial in range(a.trials):
         func, keys, kw = (ALL if a.all else FUNCS)[rng.integers(len(ALL if a.all else FUNCS))]
@@ -135,7 +157,6 @@ def main():
                 bad += 1
                 print(f"trial {trial} {func}[{k}] {kinds} shapes {[np.shape(o) for o in ops]}: want {w.shape} {w.dtype}, got {g.shape} {g.dtype}"
                       + ("" if w.shape != g.shape else f" max rel {float(np.nanmax(np.abs(g.astype(np.float64) - w) / np.abs(w))):.2e}"))
-    print(f"shape fuzz: {a.trials} trials, {bad} differences")
     return bad
 
 
