@@ -239,6 +239,8 @@ def run(name, args, ints=(), eps=None, dtype=None):
 # plain promotion were recorded from the reference (tests/golden/gen_dtype_rules.py -> _dtype_rules.RULES, data only) and
 # are applied to what a NumPy call returns; the arithmetic keeps the promotion's type (a float64 result of float32
 # arithmetic is what the reference has there, too).  DeviceArrays and other libraries' arrays keep their own types.
+from ._dtype_rules import RULES as _DTYPE_RULES  # noqa: E402  (data only)
+
 _BISECTING = frozenset(("temperature_on_moist_adiabat", "wet_bulb_temperature_from_dewpoint", "wet_bulb_temperature_from_specific_humidity",
                         "wet_bulb_potential_temperature_from_dewpoint", "wet_bulb_potential_temperature_from_specific_humidity"))
 
@@ -255,11 +257,9 @@ def _kind_of(a):
 
 
 def _as_the_reference_types_them(name, ints, args, outs):
-    from ._dtype_rules import RULES
-
     lcl = name == "lcl"
     ints = tuple(int(i) for i in ints)
-    rules = RULES.get((name, ints))
+    rules = _DTYPE_RULES.get((name, ints))
     # the reference's bisection works on atleast_1d(theta_e): operands that are all 0-d come back with shape (1,), not ()
     one_d = name in _BISECTING and len(ints) == 2 and ints[1] == 0 and len(outs) == 1 and np.ndim(outs[0]) == 0
     if rules is None and not lcl and not one_d:
