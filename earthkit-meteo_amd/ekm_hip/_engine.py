@@ -262,7 +262,11 @@ def _as_the_reference_types_them(name, ints, args, outs):
     rules = _DTYPE_RULES.get((name, ints))
     # the reference's bisection works on atleast_1d(theta_e): operands that are all 0-d come back with shape (1,), not ()
     one_d = name in _BISECTING and len(ints) == 2 and ints[1] == 0 and len(outs) == 1 and np.ndim(outs[0]) == 0
-    if rules is None and not lcl and not one_d:
+    # ... and temperature_on_moist_adiabat writes into an array of theta_e's shape: a one-element p of more dimensions ([1, 1]
+    # beside theta_e of [n]) does not add them (where p has more elements than that the reference raises)
+    like_ept = (name == "temperature_on_moist_adiabat" and len(outs) == 1 and np.ndim(args[1]) > np.ndim(args[0]) >= 1
+                and np.size(args[1]) == 1 and isinstance(outs[0], np.ndarray))
+    if rules is None and not lcl and not one_d and not like_ept:
         return outs
     kinds = [_kind_of(a) for a in args]
     if None in kinds or not all(isinstance(o, (np.ndarray, np.generic)) for o in outs):
@@ -270,6 +274,8 @@ def _as_the_reference_types_them(name, ints, args, outs):
     outs = list(outs)
     if one_d:
         outs[0] = np.asarray(outs[0]).reshape(1)
+    if like_ept:
+        outs[0] = outs[0].reshape(np.shape(args[0]))
     chars = (rules or {}).get("".join(kinds))
     if chars is not None:
         outs = [np.asarray(o).astype(_F32 if c == "f" else _F64, copy=False) if np.ndim(o) else (np.float32 if c == "f" else np.float64)(o)

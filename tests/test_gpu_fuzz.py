@@ -249,6 +249,8 @@ def test_random_shapes_dtypes_and_layouts_through_the_numpy_path(ek):
     try:
         sys.argv = ["shape_fuzz.py", "--trials", "300"]
         assert mod.main() == 0
+        sys.argv = ["shape_fuzz.py", "--trials", "1000", "--all", "--seed", "7"]  # drawn from all 94 function x variant cases
+        assert mod.main() == 0
         sys.argv = ["shape_fuzz.py", "--trials", "300", "--device"]  # the same calls with DeviceArray operands: shapes and values
         assert mod.main() == 0
     finally:

@@ -145,6 +145,8 @@ def _trials(a, rng, ek, orc):
             # a float32 t carries 2.5e-6), the library computes everything in float64 -- the comparison is float32-grade there
             mixed = any(k.startswith(("f32", "zerod")) for k in kinds)
             tol = 1e-4 if w.dtype == np.float32 else (1e-5 if mixed else 1e-7)
+            if kw.get("t_method") == "bisect":
+                tol = max(tol, 2.1 * (120.0 / 4096) / 230.0)  # a sign that is rounding noise moves the search by up to two quanta
             if a.device:  # the promotion's dtype (float32 unless an operand is float64): compare there
                 w = w.astype(g.dtype)
                 if func == "lcl" and k == 0 and w.shape != g.shape:
