@@ -998,6 +998,9 @@ EKM_HD unsigned bisect_heap_child(unsigned node, float nr) {
 // D of one node (fp32): positive <=> the residual is positive, unless |D| <= the band (then `amb`); returned NEGATED.  w = the positive
 // denominator the exact step divides by (ifs: p + (eps-1)*es; Bolton: p - es); thr0 = the part of the band that goes with p.
 constexpr double kB35WsExact = 2.0;
+#ifndef EKM_B35_FOLD
+#define EKM_B35_FOLD 1  // kl folded into the logarithm the walk carries (A/B: 0 subtracts it at every step)
+#endif
 
 
 // The reference's bolton35 residual as it stands, theta_e*exp(G_sat(scale=-1)) - th_sat (thermo.py:1075, 1215-1224), in
@@ -1046,7 +1049,7 @@ EKM_HD float bisect_fast_test(float es, float a, float u, float p, float kl, flo
     w = p - es;
     const float ees = float(k::eps) * es;
     scale = ees * m_fnma(0.28f, kl, a);
-    D = m_fms(u - kl, w, scale);
+    D = m_fms(EKM_B35_FOLD ? u : u - kl, w, scale);  // u = L_m - (le + kl): the walks fold kl into the logarithm they carry
     // ws = eps*es/(p - es) >= kB35WsExact: the reference's two terms, theta_e*exp(-2675*ws/t) and th_sat =
     // t*(p0/p)^(kappa*(1 - 0.28*ws)), can BOTH leave the normal range there (ws of several hundred where p - es is a
     // fraction of a pascal: 0 - 0, sign 0, the reference stays on this node for good), and D -- the residual divided
@@ -1118,6 +1121,7 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
     // a NEGATIVE te (a temperature handed over in Celsius) has no logarithm; the reference's residual te*2^g - t_m is
     // negative at every node then, as for te = 0: the same walk (all the way down, 133.19 K), not NaN
     if (METHOD == EPT_IFS && te[j] < 0.0f) lq[j] = -std::numeric_limits<float>::infinity();
+    if (METHOD == EPT_BOLTON35 && EKM_B35_FOLD) lq[j] += kl[j];  // bolton35's test takes u - kl (bisect_fast_test)
     tfix[j] = 0.0f;
   }
   constexpr int REC = heap_rec<METHOD, float>();
@@ -1274,6 +1278,7 @@ EKM_HD void t_on_ma_bisect_heap64(const T (&lte)[V], const T (&te)[V], const T (
     thr0[j] = float(1.5 * kHeapTau0) * pf[j];
     if (METHOD != EPT_IFS && !(ltef[j] < std::numeric_limits<float>::infinity())) ltef[j] = nan_v<float>();  // as in the fp32 walk
     if (METHOD == EPT_IFS && te[j] < T(0.0)) ltef[j] = -std::numeric_limits<float>::infinity();              // likewise
+    if (METHOD == EPT_BOLTON35 && EKM_B35_FOLD) ltef[j] += klf[j];
     tfix[j] = T(0.0);
   }
   constexpr int REC = heap_rec<METHOD, double>();
