@@ -149,6 +149,27 @@ def newton_amplification(t, q, p, h=1e-6, return_candidates=False):
 
 
 def misses_explained(f, xs, got, want, tol, h=1e-6, unit=2.0 ** -24, factor=8.0):
+    """`_misses_explained_at` at the perturbation scales h, h/3, h/10 and h/30: a POLE of the reference inside +-h (bolton35's
+    one Newton step at p within 1e-7 of where its dlnf crosses zero: theta_e 436.42 K, p 99975.96 Pa gives 518.6 K, 751.0 K at
+    p*(1 - 1e-7), NaN at p*(1 - 3e-7), 260.0 K at p*(1 - 1e-6)) hides from the +-h secant and from the span of its outcomes;
+    the smaller scales -- still of the size of an fp32 rounding of the input -- see it.  A point is explained if any
+    scale explains it."""
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    xs = [np.asarray(a, np.float64) for a in xs]
+    finite = np.zeros(got.shape, bool)
+    on_edge = np.zeros(got.shape, bool)
+    for scale in (1.0, 1.0 / 3.0, 0.1, 1.0 / 30.0):
+        todo = np.flatnonzero(~(finite | on_edge))
+        if not todo.size:
+            break
+        fi, ed = _misses_explained_at(f, [a[todo] if a.ndim else a for a in xs], got[todo], want[todo], tol, h * scale, unit, factor)
+        finite[todo] |= fi
+        on_edge[todo] |= ed
+    return finite, on_edge
+
+
+def _misses_explained_at(f, xs, got, want, tol, h=1e-6, unit=2.0 ** -24, factor=8.0):
     """Which deviations of `got` from the reference's `want` (same dtype run) the reference's own conditioning explains
     -- from the fp64 oracle `f` alone, never from `got`.  Returns two masks over the points:
       * finite kappa: the deviation is within factor x kappa x unit (kappa: `amplification`; unit: the rounding unit of
