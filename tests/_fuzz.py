@@ -61,7 +61,11 @@ def head(d, n=MORE_POINTS):
     return {k: v[:n] for k, v in d.items()}
 
 
-def make(n=N_POINTS, seed=SEED, dtype=np.float32):
+def make(n=N_POINTS, seed=SEED, dtype=np.float32, adversarial=False):
+    """`adversarial`: after the draws, 60 % of the points are moved next to the places where the reference's own arithmetic
+    turns: the pressure within 1e-2 ... 1e-7 of es at one of the search tree's first 127 nodes (the NaN rule, bolton35's
+    underflow region), within 1e-3 ... 1e-7 of p0 (bolton35's Newton pole), the dewpoint equal to the temperature (a
+    saturated parcel).  tools/fuzz_sweep.py --adversarial; the suites run the plain draw."""
     r = np.random.default_rng(seed)
     d = dict(t=r.uniform(150.0, 400.0, n),
              p=np.exp(r.uniform(np.log(1.0), np.log(1.26e5), n)),
@@ -69,6 +73,19 @@ def make(n=N_POINTS, seed=SEED, dtype=np.float32):
              ept=np.exp(r.uniform(np.log(150.0), np.log(3000.0), n)))
     d["td"] = d["t"] - r.uniform(0.0, 60.0, n)  # (drawn last: the four above are what they were before this one existed)
     d["r"] = r.uniform(0.5, 120.0, n)          # relative humidity in per cent (drawn after td, for the same reason)
+    if adversarial:
+        from oracle import thermo_oracle as orc_
+        ra = np.random.default_rng(seed + 1)
+        kind = ra.integers(0, 10, n)
+        depth = ra.integers(0, 7, n)
+        j = (ra.random(n) * (2 ** depth)).astype(np.int64)
+        node_t = (273.16 - 20.0) - 60.0 + (2 * j + 1) * (60.0 / 2 ** depth)  # lattice temperature of node j at that depth
+        with np.errstate(all="ignore"):
+            es_node = orc_.saturation_vapour_pressure(node_t.astype(dtype)).astype(np.float64)
+        near = 1.0 + ra.choice([-1.0, 1.0], n) * 10.0 ** (-ra.uniform(2.0, 7.0, n))
+        d["p"] = np.where(kind < 4, np.clip(es_node * near, 1.0, 1.26e5), d["p"])
+        d["p"] = np.where(kind == 4, 1e5 * (1.0 + ra.choice([-1.0, 1.0], n) * 10.0 ** (-ra.uniform(3.0, 7.0, n))), d["p"])
+        d["td"] = np.where(kind == 5, d["t"], d["td"])
     d = {k: v.astype(dtype) for k, v in d.items()}
     # the other operands the 39 functions take (tests/golden/_case_table.py), derived from the draws in the dtype under test
     from oracle import thermo_oracle as orc

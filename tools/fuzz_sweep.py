@@ -26,7 +26,7 @@ def twin_sweep(a):
     for s in range(a.seeds):
         seed = a.first_seed + 17 * s
         for tag, dtype in (("f32", np.float32), ("f64", np.float64)):
-            d = _fuzz.make(a.n, seed, dtype)
+            d = _fuzz.make(a.n, seed, dtype, a.adversarial)
             for func, keys, method, tm in _fuzz.CASES + _fuzz.CASES_MORE:
                 ins, kw = [d[k] for k in keys], dict(ept_method=method, t_method=tm)
                 os.environ.pop("EKM_TWIN_BISECT_EXACT", None)
@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--seeds", type=int, default=3)
     ap.add_argument("--n", type=int, default=1 << 22)
     ap.add_argument("--first-seed", type=int, default=1000)
+    ap.add_argument("--adversarial", action="store_true", help="tests/_fuzz.py::make(adversarial=True): points moved next to the "
+                    "search tree's node pressures, to p0 and to saturation")
     ap.add_argument("--twin", action="store_true", help="run the host twin instead of the GPU")
     a = ap.parse_args()
     np.seterr(all="ignore")
@@ -61,7 +63,7 @@ def main():
     for s in range(a.seeds):
         seed = a.first_seed + 17 * s
         for tag, dtype in (("f32", np.float32), ("f64", np.float64)):
-            d = _fuzz.make(a.n, seed, dtype)
+            d = _fuzz.make(a.n, seed, dtype, a.adversarial)
             dd = {k: ekm_hip.to_device(v) for k, v in d.items()}
             for func, keys, method, tm in _fuzz.CASES + _fuzz.CASES_MORE:
                 ins = [dd[k] for k in keys]
