@@ -30,6 +30,21 @@ def test_fuzz_against_the_oracle(points, func, keys, method, t_method):
     print(_fuzz.judge(func, keys, method, t_method, tag, d, got))
 
 
+@pytest.fixture(scope="module", params=["f32", "f64"])
+def adversarial(request):
+    dtype = np.float32 if request.param == "f32" else np.float64
+    return request.param, dtype, _fuzz.make(n=_fuzz.MORE_POINTS, seed=_fuzz.SEED + 1, dtype=dtype, adversarial=True)
+
+
+@pytest.mark.parametrize("func,keys,method,t_method", _fuzz.CASES, ids=[f"{f.split('_')[0]}-{m}-{tm}" for f, _, m, tm in _fuzz.CASES])
+def test_fuzz_next_to_the_node_pressures_p0_and_saturation(adversarial, func, keys, method, t_method):
+    """_fuzz.make(adversarial=True): 60 % of the points within 1e-2 ... 1e-7 of es at one of the tree's first 127 nodes, within
+    1e-3 ... 1e-7 of p0, or saturated (td = t)."""
+    tag, dtype, d = adversarial
+    got = twin.by_reference_name(func, [d[k] for k in keys], dict(ept_method=method, t_method=t_method), dtype)
+    print(_fuzz.judge(func, keys, method, t_method, tag, d, got))
+
+
 @pytest.mark.parametrize("func,keys,method,t_method", _fuzz.CASES_MORE,
                          ids=[f"{'-'.join(f.split('_')[:3] + f.split('_')[-1:])}-{m}-{tm}" for f, _, m, tm in _fuzz.CASES_MORE])
 def test_fuzz_of_the_other_callers_of_the_inversions(points, func, keys, method, t_method):
