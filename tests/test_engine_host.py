@@ -1,5 +1,6 @@
 """Host logic of ekm_hip that needs no GPU: operand classification (what is handed to the
 kernels as a field / scalar / level vector), dtype promotion, sharding, error conventions."""
+import os
 import numpy as np
 import pytest
 
@@ -237,3 +238,15 @@ def test_results_are_typed_as_the_reference_types_them():
         assert len(ints) == len(OPS[name][2])
         for kinds, chars in rules.items():
             assert len(kinds) == nin and set(kinds) <= set("fds") and len(chars) == nout and set(chars) <= set("fd")
+
+
+@pytest.mark.skipif(not os.path.isdir(os.environ.get("EKM_REFERENCE", "/root/reference")), reason="the reference is only in the build container")
+def test_the_typing_table_regenerates_from_the_reference(tmp_path):
+    """ekm_hip/_dtype_rules.py is what tests/golden/gen_dtype_rules.py records from the reference today, byte for byte."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "rules.py"
+    subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "gen_dtype_rules.py"), str(out)], check=True, capture_output=True, timeout=600)
+    assert out.read_text() == open(os.path.join(root, "earthkit-meteo_amd", "ekm_hip", "_dtype_rules.py")).read()
