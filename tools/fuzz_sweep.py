@@ -31,7 +31,7 @@ def twin_sweep(a):
                 ins, kw = [d[k] for k in keys], dict(ept_method=method, t_method=tm)
                 os.environ.pop("EKM_TWIN_BISECT_EXACT", None)
                 got = twin.by_reference_name(func, ins, kw, dtype)
-                line = _fuzz.judge(func, keys, method, tm, tag, d, got)
+                line = _fuzz.judge(func, keys, method, tm, tag, d, got, limits=a.adversarial != 2)
                 if tm == "bisect":
                     os.environ["EKM_TWIN_BISECT_EXACT"] = "1"
                     e = twin.by_reference_name(func, ins, kw, dtype)
@@ -48,8 +48,9 @@ def main():
     ap.add_argument("--seeds", type=int, default=3)
     ap.add_argument("--n", type=int, default=1 << 22)
     ap.add_argument("--first-seed", type=int, default=1000)
-    ap.add_argument("--adversarial", action="store_true", help="tests/_fuzz.py::make(adversarial=True): points moved next to the "
-                    "search tree's node pressures, to p0 and to saturation")
+    ap.add_argument("--adversarial", type=int, default=0, nargs="?", const=1, help="tests/_fuzz.py::make(adversarial=N): 1 = points moved "
+                    "next to the search tree's node pressures, to p0 and to saturation; 2 = also theta_e next to the Davies-Jones "
+                    "regime thresholds (then without the limits on how many points may need an explanation)")
     ap.add_argument("--twin", action="store_true", help="run the host twin instead of the GPU")
     a = ap.parse_args()
     np.seterr(all="ignore")
@@ -70,7 +71,7 @@ def main():
                 out = getattr(ekm_hip.thermo, func)(*ins, ept_method=method, t_method=tm)
                 got = out.to_host()
                 out.free()
-                line = _fuzz.judge(func, keys, method, tm, tag, d, got)
+                line = _fuzz.judge(func, keys, method, tm, tag, d, got, limits=a.adversarial != 2)
                 if tm == "bisect":
                     _ffi.check(lib.ekm_set_tuning_param(b"bisect_exact", 1))
                     ex = getattr(ekm_hip.thermo, func)(*ins, ept_method=method, t_method=tm)
