@@ -241,8 +241,8 @@ def run(name, args, ints=(), eps=None, dtype=None):
 # arithmetic is what the reference has there, too).  DeviceArrays and other libraries' arrays keep their own types.
 from ._dtype_rules import RULES as _DTYPE_RULES  # noqa: E402  (data only)
 
-_BISECTING = frozenset(("temperature_on_moist_adiabat", "wet_bulb_temperature_from_dewpoint", "wet_bulb_temperature_from_specific_humidity",
-                        "wet_bulb_potential_temperature_from_dewpoint", "wet_bulb_potential_temperature_from_specific_humidity"))
+_SHAPED = frozenset(("lcl", "temperature_on_moist_adiabat", "wet_bulb_temperature_from_dewpoint", "wet_bulb_temperature_from_specific_humidity",
+                     "wet_bulb_potential_temperature_from_dewpoint", "wet_bulb_potential_temperature_from_specific_humidity"))
 
 
 def _kind_of(a):
@@ -257,26 +257,37 @@ def _kind_of(a):
 
 
 def _as_the_reference_types_them(name, ints, args, outs):
-    lcl = name == "lcl"
-    ints = tuple(int(i) for i in ints)
+    if type(ints) is not tuple or (ints and type(ints[0]) is not int):
+        ints = tuple(int(i) for i in ints)
     rules = _DTYPE_RULES.get((name, ints))
-    # the reference's bisection works on atleast_1d(theta_e): operands that are all 0-d come back with shape (1,), not ()
-    one_d = name in _BISECTING and len(ints) == 2 and ints[1] == 0 and len(outs) == 1 and np.ndim(outs[0]) == 0
-    # ... and temperature_on_moist_adiabat writes into an array of theta_e's shape: a one-element p of more dimensions ([1, 1]
-    # beside theta_e of [n]) does not add them (where p has more elements than that the reference raises)
-    like_ept = (name == "temperature_on_moist_adiabat" and len(outs) == 1 and np.ndim(args[1]) > np.ndim(args[0]) >= 1
-                and np.size(args[1]) == 1 and isinstance(outs[0], np.ndarray))
-    if rules is None and not lcl and not one_d and not like_ept:
+    lcl = one_d = like_ept = False
+    if name in _SHAPED:
+        lcl = name == "lcl"
+        # the reference's bisection works on atleast_1d(theta_e): operands that are all 0-d come back with shape (1,), not ()
+        one_d = not lcl and len(ints) == 2 and ints[1] == 0 and len(outs) == 1 and np.ndim(outs[0]) == 0
+        # ... and temperature_on_moist_adiabat writes into an array of theta_e's shape: a one-element p of more dimensions ([1, 1]
+        # beside theta_e of [n]) does not add them (where p has more elements than that the reference raises)
+        like_ept = (name == "temperature_on_moist_adiabat" and len(outs) == 1 and np.ndim(args[1]) > np.ndim(args[0]) >= 1
+                    and np.size(args[1]) == 1 and isinstance(outs[0], np.ndarray))
+    if rules is None and not (lcl or one_d or like_ept):
         return outs
-    kinds = [_kind_of(a) for a in args]
-    if None in kinds or not all(isinstance(o, (np.ndarray, np.generic)) for o in outs):
+    kinds = ""
+    for a in args:
+        k = _kind_of(a)
+        if k is None:
+            return outs
+        kinds += k
+    for o in outs:
+        if not isinstance(o, (np.ndarray, np.generic)):
+            return outs
+    chars = rules.get(kinds) if rules is not None else None
+    if chars is None and not (lcl or one_d or like_ept):
         return outs
     outs = list(outs)
     if one_d:
         outs[0] = np.asarray(outs[0]).reshape(1)
     if like_ept:
         outs[0] = outs[0].reshape(np.shape(args[0]))
-    chars = (rules or {}).get("".join(kinds))
     if chars is not None:
         outs = [np.asarray(o).astype(_F32 if c == "f" else _F64, copy=False) if np.ndim(o) else (np.float32 if c == "f" else np.float64)(o)
                 for o, c in zip(outs, chars)]
