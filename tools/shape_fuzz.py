@@ -145,6 +145,8 @@ def _trials(a, rng, ek, orc):
             # a float32 t carries 2.5e-6), the library computes everything in float64 -- the comparison is float32-grade there
             mixed = any(k.startswith(("f32", "zerod")) for k in kinds)
             tol = 1e-4 if w.dtype == np.float32 else (1e-5 if mixed else 1e-7)
+            if mixed and kw.get("t_method") == "newton" and w.dtype == np.float64:
+                tol = 2e-3  # the reference's theta_e is float32 there, and bolton35's one Newton step amplifies 1e-7 of it a thousandfold
             if kw.get("t_method") == "bisect":
                 tol = max(tol, 2.1 * (120.0 / 4096) / 230.0)  # a sign that is rounding noise moves the search by up to two quanta
             if a.device:  # the promotion's dtype (float32 unless an operand is float64): compare there
@@ -157,7 +159,7 @@ def _trials(a, rng, ek, orc):
                 ok = np.array_equal(np.isnan(w), np.isnan(g)) and (not both.any() or float(np.max(np.abs(g[both] - w[both]) / np.maximum(np.abs(w[both]), 1e-30))) <= tol)
             if not ok:
                 bad += 1
-                print(f"trial {trial} {func}[{k}] {kinds} shapes {[np.shape(o) for o in ops]}: want {w.shape} {w.dtype}, got {g.shape} {g.dtype}"
+                print(f"trial {trial} {func}{kw}[{k}] {kinds} shapes {[np.shape(o) for o in ops]}: want {w.shape} {w.dtype}, got {g.shape} {g.dtype}"
                       + ("" if w.shape != g.shape else f" max rel {float(np.nanmax(np.abs(g.astype(np.float64) - w) / np.abs(w))):.2e}"))
     return bad
 
