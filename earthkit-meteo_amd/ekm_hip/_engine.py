@@ -241,6 +241,9 @@ def run(name, args, ints=(), eps=None, dtype=None):
 # arithmetic is what the reference has there, too).  DeviceArrays and other libraries' arrays keep their own types.
 from ._dtype_rules import RULES as _DTYPE_RULES  # noqa: E402  (data only)
 
+# a result that is a scalar: np.float32 / np.float64, or -- calls on Python scalars alone -- a Python float where the reference's
+# function is plain arithmetic on them ('p') and a 0-d array where it fills a result buffer ('a')
+_SCALAR_AS = {"f": np.float32, "d": np.float64, "p": float, "a": np.asarray}
 _SHAPED = frozenset(("lcl", "temperature_on_moist_adiabat", "wet_bulb_temperature_from_dewpoint", "wet_bulb_temperature_from_specific_humidity",
                      "wet_bulb_potential_temperature_from_dewpoint", "wet_bulb_potential_temperature_from_specific_humidity"))
 
@@ -281,6 +284,11 @@ def _as_the_reference_types_them(name, ints, args, outs):
         if not isinstance(o, (np.ndarray, np.generic)):
             return outs
     chars = rules.get(kinds) if rules is not None else None
+    if chars is None and rules is not None and np.ndim(outs[0]) == 0:
+        # a function that fills a result buffer returns a 0-d ARRAY for 0-d operands of any kind (recorded for Python scalars)
+        alone = rules.get("s" * len(args))
+        if alone is not None and "a" in alone:
+            chars = "".join("a" if c == "a" else ("f" if np.asarray(o).dtype == _F32 else "d") for c, o in zip(alone, outs))
     if chars is None and not (lcl or one_d or like_ept):
         return outs
     outs = list(outs)
@@ -289,8 +297,7 @@ def _as_the_reference_types_them(name, ints, args, outs):
     if like_ept:
         outs[0] = outs[0].reshape(np.shape(args[0]))
     if chars is not None:
-        outs = [np.asarray(o).astype(_F32 if c == "f" else _F64, copy=False) if np.ndim(o) else (np.float32 if c == "f" else np.float64)(o)
-                for o, c in zip(outs, chars)]
+        outs = [np.asarray(o).astype(_F32 if c == "f" else _F64, copy=False) if np.ndim(o) else _SCALAR_AS[c](o) for o, c in zip(outs, chars)]
     if lcl and np.ndim(outs[0]):  # t_lcl has the shape of broadcast(t, td); the values do not vary along p's own axes
         full = np.shape(outs[0])
         want = np.broadcast_shapes(np.shape(args[0]), np.shape(args[1]))
@@ -298,6 +305,8 @@ def _as_the_reference_types_them(name, ints, args, outs):
             padded = (1,) * (len(full) - len(want)) + tuple(want)
             t_lcl = np.asarray(outs[0])[tuple(slice(None) if w == f else slice(0, 1) for w, f in zip(padded, full))].reshape(want)
             outs[0] = t_lcl.copy() if t_lcl.ndim else t_lcl.dtype.type(t_lcl)
+    if lcl and kinds[:2] == "ss" and np.ndim(outs[0]) == 0 and rules is not None and rules.get("sss", "d")[0] == "p":
+        outs[0] = float(outs[0])  # davies' t_lcl of two Python floats is plain arithmetic on them: a Python float, whatever p is
     return tuple(outs)
 
 

@@ -237,7 +237,17 @@ def test_results_are_typed_as_the_reference_types_them():
         nin, nout = len(OPS[name][0]), len(OPS[name][1])
         assert len(ints) == len(OPS[name][2])
         for kinds, chars in rules.items():
-            assert len(kinds) == nin and set(kinds) <= set("fds") and len(chars) == nout and set(chars) <= set("fd")
+            assert len(kinds) == nin and set(kinds) <= set("fds") and len(chars) == nout
+            assert set(chars) <= (set("dpa") if set(kinds) == {"s"} else set("fd"))
+    # calls on Python scalars alone: a Python float where the reference's function is plain arithmetic, a 0-d array where it
+    # fills a result buffer (saturation_vapour_pressure, phase "mixed"), np.float64 otherwise
+    from ekm_hip.thermo import PHASE
+    out = e._as_the_reference_types_them("celsius_to_kelvin", (), (7.0,), (np.float64(280.16),))
+    assert type(out[0]) is float
+    out = e._as_the_reference_types_them("saturation_vapour_pressure", (PHASE["mixed"],), (280.0,), (np.float64(991.0),))
+    assert isinstance(out[0], np.ndarray) and out[0].shape == () and out[0].dtype == np.float64
+    out = e._as_the_reference_types_them("potential_temperature", (), (280.0, 9e4), (np.float64(288.0),))
+    assert type(out[0]) is np.float64
 
 
 @pytest.mark.skipif(not os.path.isdir(os.environ.get("EKM_REFERENCE", "/root/reference")), reason="the reference is only in the build container")
