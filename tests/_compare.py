@@ -9,8 +9,10 @@ result is quantised to 120/4096 K; a rounding-level difference in the residual
 flips one `sign()` and moves the answer by up to two quanta (0.0586 K ~ 2e-4
 relative).  The reference's own tests use rtol=1e-3 for wet-bulb for this
 reason (tests/thermo/test_thermo.py:802 there).  For bisect outputs the bar is
-therefore: every point within 2 quanta, and at most `BISECT_FLIP_FRACTION` of
-the points off by more than the plain tolerance.
+therefore: every point within 2 quanta, and at most `BISECT_FLIP_LIMIT[dtype]`
+of the points the reference decides stably off the reference's lattice value at
+all (budgets re-based in round 6 on what the MI355X runs actually used, see
+`bisect_flip_allowed`).
 
 At exactly saturated points (t == tw) the residual of the very first steps is
 ~0 and its sign is pure rounding noise; one early flip can send the search into
@@ -30,7 +32,20 @@ RTOL = {"f64": 1e-6, "f32": 1e-4}
 # fp64: the bar is 1e-6; the primitives are built to ~2e-9 (csrc/thermo_math.hpp) and every fp64 assertion of the GPU suite is this
 F64_ASSERT = 1e-7
 BISECT_QUANTUM = 120.0 / 4096.0
-BISECT_FLIP_FRACTION = 0.02
+# Stable bisect points that may sit on another lattice value than the reference's.  Measured (round 5, 178 checks on the
+# MI355X, 32,344,340 stable points): ONE point off, in fp64 (bolton35 fuzz, 1 of 1,048,576); the host twin: 0 of
+# 14,193,996.  Round 5's limit was a flat 2 % -- ten thousand times that use; VERDICT r5 showed a run with 1 % of the
+# points moved by two quanta passing.  Now: a fraction of the points per dtype, nothing at all below 100,000 points.
+BISECT_FLIP_LIMIT = {"f32": 1e-5, "f64": 2e-6}
+BISECT_FLIP_MIN_POINTS = 100_000
+# the share of ALL points (stable or not) that must carry the reference's very bits on a non-adversarial draw
+# (measured: 99.987-99.994 % in fp32, 100 % in fp64 on 400 k points; the suites: >= 99.98 %)
+BISECT_MIN_IDENTICAL = 0.999
+
+
+def bisect_flip_allowed(tag, n):
+    """How many of n stable points may differ from the reference's lattice value (by one or two quanta)."""
+    return int(np.ceil(BISECT_FLIP_LIMIT[tag] * n)) if n >= BISECT_FLIP_MIN_POINTS else 0
 
 
 def rel_err(got, want):
@@ -108,7 +123,7 @@ def assert_parity(got, want, tag, what, bisect=False, rtol=None, unstable=None, 
     rtol = RTOL[tag] if rtol is None else rtol
     boundary = None
     if bisect:
-        return _assert_bisect(got, want, what, rtol, unstable, ref64, noise_t)
+        return _assert_bisect(got, want, what, rtol, unstable, ref64, noise_t, tag)
     if unstable is not None and np.any(unstable):
         unstable = np.asarray(unstable).ravel()
         lim = max(3, 2e-4 * unstable.size)
@@ -141,12 +156,12 @@ def assert_parity(got, want, tag, what, bisect=False, rtol=None, unstable=None, 
     return worst
 
 
-def _assert_bisect(got, want, what, rtol, unstable, ref64, noise_t=None):
+def _assert_bisect(got, want, what, rtol, unstable, ref64, noise_t=None, tag="f32"):
     """The 12-step sign search (the reference's default t_method), result quantised to 120/4096 K.
 
     Every point -- reference-unstable or not -- is CHECKED:
       * points the reference decides stably: identical NaN / inf pattern, within 2 quanta, at most
-        BISECT_FLIP_FRACTION of them one or two quanta off;
+        bisect_flip_allowed(dtype, n) of them one or two quanta off (any difference from the reference's lattice value counts);
       * reference-unstable points (`unstable`: the reference's own residual is below rounding noise at some step, or
         its fp32 and fp64 runs disagree -- identified from the oracle, never from the output under test; counted,
         limit BISECT_UNSTABLE_FRACTION):
@@ -199,7 +214,11 @@ def _assert_bisect(got, want, what, rtol, unstable, ref64, noise_t=None):
                 undecidable, lim, int(uns.sum()))
         assert undecidable <= lim, f"{what}: {undecidable} unanchored differences on {uns.sum()} unstable points"
     r = rel_err(got, want)
-    flips = int((r[st] > rtol).sum())
-    _record(what, "bisect: stable points one or two quanta off", flips, max(1, BISECT_FLIP_FRACTION * r.size), r.size)
-    assert flips <= max(1, BISECT_FLIP_FRACTION * r.size), f"{what}: {flips}/{r.size} bisect sign flips"
+    # a flip = a stable point on ANOTHER lattice value (results are lattice temperatures: half a quantum tells them apart;
+    # the relative bar alone would miss a one-quantum flip above 293 K in fp32, 0.0293/300 < 1e-4)
+    with np.errstate(all="ignore"):
+        flips = int((st & np.isfinite(got) & np.isfinite(want) & (d > 0.5 * BISECT_QUANTUM)).sum())
+    allowed = bisect_flip_allowed(tag, int(st.sum()))
+    _record(what, "bisect: stable points one or two quanta off", flips, allowed, int(st.sum()))
+    assert flips <= allowed, f"{what}: {flips}/{int(st.sum())} stable bisect points off the reference's lattice value (allowed {allowed})"
     return float(r[st].max()) if st.any() else 0.0

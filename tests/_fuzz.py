@@ -31,7 +31,8 @@ What is asserted, against the oracle run in the SAME dtype (the oracle is pinned
 """
 import numpy as np
 
-from _compare import CENSUS, ILL_CONDITIONED_FRACTION, _record, assert_parity, bisect_sign_noise, bisect_unstable, rel_err
+from _compare import (BISECT_MIN_IDENTICAL, CENSUS, ILL_CONDITIONED_FRACTION, _record, assert_parity, bisect_sign_noise,
+                      bisect_unstable, rel_err)
 
 N_POINTS = 1 << 20
 SEED = 20261004
@@ -42,6 +43,20 @@ KAPPA_FACTOR = 16.0         # measured on the host twin: <= 9.1
 MAX_STEP = 10.0             # ... and its Newton step a correction of the guess (benchmark distribution: <= 5.0 K)
 F64_ASSERT = 1e-7           # fp64 bar 1e-6; asserted one order inside it
 UNIT = {"f32": 2.0 ** -24, "f64": 2e-10}  # rounding unit of the arithmetic under test (fp64: the primitives' accuracy)
+
+# How many points of ONE check may sit on each of the reference's own rounding edges (round 6: re-based on the largest use
+# seen in the suites, host twin and MI355X, profiles/r06_parity_budgets.txt; round 5 allowed max(3, 1e-5 n) for all of them).
+# An edge nobody has hit in the suites' draws gets no allowance there: tools/fuzz_sweep.py, which draws other seeds and the
+# adversarial sets, passes limits=False and reports the counts instead.
+
+
+def edge_allowed(kind, n, sweep=False):
+    if sweep:  # other seeds, millions of points (tools/fuzz_sweep.py): the edges do turn up there, a handful per million
+        return max(3, int(1e-5 * n))
+    frac = {"bisect_nan_rule": 0.0, "newton_es_underflow": 0.0, "newton_nan_rule": 0.0,   # measured 0 of 14 M / 37 M points
+            "newton_tw_zero": 4e-6, "newton_denominator": 4e-6}[kind]                     # measured <= 2 of 1,048,576
+    return int(np.ceil(frac * n)) if frac else 0
+
 
 METHODS = ("ifs", "bolton35", "bolton39")
 T_METHODS = ("bisect", "newton")
@@ -106,9 +121,11 @@ def make(n=N_POINTS, seed=SEED, dtype=np.float32, adversarial=False):
     return d
 
 
-def judge(func, keys, method, t_method, tag, d, got, limits=True):
+def judge(func, keys, method, t_method, tag, d, got, limits=True, min_identical=BISECT_MIN_IDENTICAL, sweep=False):
     """Raises AssertionError on a real miss; returns the line that goes into the terminal summary.  `limits=False`: every
-    deviation must still be explained, but how MANY points may need an explanation is not asserted (an adversarial draw)."""
+    deviation must still be explained, but how MANY points may need an explanation is not asserted (an adversarial draw).
+    `min_identical` (bisection): the share of all points that must carry the oracle's very bits (an adversarial draw, most
+    of whose points sit ON the reference's own rounding edges, passes its own figure)."""
     from oracle import conditioning
     from oracle import thermo_oracle as orc
 
@@ -132,12 +149,13 @@ def judge(func, keys, method, t_method, tag, d, got, limits=True):
         edge = conditioning.bisect_nan_rule_noise(func, ins, kwargs, 4e-6 if tag == "f32" else 1e-13)
         edge &= np.isnan(got) != np.isnan(want)
         _record(what, "bisect fuzz: NaN on one side where p - es(t_node) is within rounding of the 1e-4 threshold", int(edge.sum()),
-                max(3, 1e-5 * n), n)
-        assert edge.sum() <= max(3, 1e-5 * n), (what, int(edge.sum()))
+                edge_allowed("bisect_nan_rule", n, sweep), n)
+        assert edge.sum() <= edge_allowed("bisect_nan_rule", n, sweep) or not limits, (what, int(edge.sum()))
         if edge.any():
             got = np.where(edge, want, got)
         worst = assert_parity(got, want, tag, what, bisect=True, unstable=unstable, ref64=ref64, noise_t=noise_t)
         same = float(np.mean((got == want) | (np.isnan(got) & np.isnan(want))))
+        assert same >= min_identical, f"{what}: only {same:.5%} of the points bit-identical to the oracle (required {min_identical:.3%})"
         line = f"{what}: {n} points, {same:.5%} bit-identical, {int(unstable.sum())} reference-unstable (all anchored), worst stable {worst:.2e}"
         CENSUS.append(line)
         return line
@@ -188,15 +206,15 @@ def judge(func, keys, method, t_method, tag, d, got, limits=True):
             te64 = (e64 * np.power(p64 / orc.p0, orc.kappa)).reshape(w64.shape)
         edge_es = nanmm & (np.abs(te64 / 48.175797 - 1.0) < 2e-6)
         _record(what, "newton fuzz: NaN on one side within 2e-6 of the fp32 es-underflow temperature 48.175797 K", int(edge_es.sum()),
-                max(3, 1e-5 * n), n)
-        assert edge_es.sum() <= max(3, 1e-5 * n), (what, int(edge_es.sum()))
+                edge_allowed("newton_es_underflow", n, sweep), n)
+        assert edge_es.sum() <= edge_allowed("newton_es_underflow", n, sweep) or not limits, (what, int(edge_es.sum()))
     # the reference's `tw <= 0 -> NaN` edge (thermo.py:1155): where guess - step cancels to within the rounding bound of
     # zero, the SIGN of the result is the fp32 reference's own rounding; NaN on either side is its outcome
     with np.errstate(all="ignore"):
         edge_zero = nanmm & (np.abs(tw_pre) <= STEP_FACTOR * UNIT[tag] * cond_abs)
     _record(what, "newton fuzz: NaN on one side where |tw| is within its rounding bound of the tw <= 0 edge", int(edge_zero.sum()),
-            max(3, 1e-5 * n), n)
-    assert edge_zero.sum() <= max(3, 1e-5 * n), (what, int(edge_zero.sum()))
+            edge_allowed("newton_tw_zero", n, sweep), n)
+    assert edge_zero.sum() <= edge_allowed("newton_tw_zero", n, sweep) or not limits, (what, int(edge_zero.sum()))
     # the reference's `p - es < 1e-4 -> NaN` rule (thermo.py:192-196, 229-232) inside the Newton path -- es(te) in the
     # regime-1 guess, es(guess) in the step -- decided by the last bits of es: NaN on either side is the reference's own
     # rounding (t 234.566 K, q 2.339e-5, p 15.178763 Pa, bolton35: es(te = 233.9 K) is p - 1e-4 to 2e-6 of itself).  The
@@ -210,8 +228,8 @@ def judge(func, keys, method, t_method, tag, d, got, limits=True):
             edge_rule |= np.abs((p64 - esx) - 1e-4) <= th_es * esx
         edge_rule &= nanmm
     _record(what, "newton fuzz: NaN on one side where p - es(te) or p - es(guess) is within rounding of the 1e-4 threshold", int(edge_rule.sum()),
-            max(3, 1e-5 * n), n)
-    assert edge_rule.sum() <= max(3, 1e-5 * n), (what, int(edge_rule.sum()))
+            edge_allowed("newton_nan_rule", n, sweep), n)
+    assert edge_rule.sum() <= edge_allowed("newton_nan_rule", n, sweep) or not limits, (what, int(edge_rule.sum()))
     # the step's DENOMINATOR is rounding noise: dlnf = -lambda*(1/tw + ...) cancels (bolton35: to 1e-5 of its terms) and
     # the first-order bound of its own rounding, STEP_FACTOR*UNIT*eu*max(lambda/guess, |d ln f/d tw|), is a quarter of |dlnf|
     # or more -- the bound above is first order in that ratio and says nothing there; the reference's fp32 and fp64 runs
@@ -221,8 +239,8 @@ def judge(func, keys, method, t_method, tag, d, got, limits=True):
         edge_den = STEP_FACTOR * UNIT[tag] * eu * np.maximum(orc.LAMBDA / np.abs(guess), at) >= 0.25 * ad
         edge_den &= ~phys & (nanmm | (r > bar))
     _record(what, "newton fuzz: deviations where the step's denominator dlnf is within 4x its own rounding bound of zero (never an atmospheric result)",
-            int(edge_den.sum()), max(3, 1e-5 * n), n)
-    assert edge_den.sum() <= max(3, 1e-5 * n), (what, int(edge_den.sum()))
+            int(edge_den.sum()), edge_allowed("newton_denominator", n, sweep), n)
+    assert edge_den.sum() <= edge_allowed("newton_denominator", n, sweep) or not limits, (what, int(edge_den.sum()))
     # beyond every bar: the reference's conditioning with respect to its inputs must explain it (kappa / NaN edges)
     miss = (nanmm | (r > bar)) & ~edge_es & ~edge_zero & ~edge_den & ~edge_rule
     idx = np.flatnonzero(miss)
@@ -260,6 +278,13 @@ def judge(func, keys, method, t_method, tag, d, got, limits=True):
 # a finite value on the other only within a factor 1e2 of the dtype's overflow (fp32 exponentials of q = 0.9 overflow:
 # exp2-based and libm-based evaluations cross the threshold a few ulps apart).
 ABSURD = 1e6  # no quantity of this module exceeds it in SI units for atmospheric input (es(400 K) = 2.4e5 Pa)
+# Results beyond ABSURD are exponentials of 14-80 whose argument carries es: every rounding of the argument is multiplied by
+# the exponent.  Their bar is ABSURD_FACTOR x ES_UNITS x |ln|result|| x unit of the dtype -- fp32 (es carries up to 100 units,
+# thermo_math.hpp::es_slope_water): 1.3e-3 at 1e6, 7.6e-3 at e^80; measured on the host twin and the MI355X: <= 482 of the
+# 1600 units (r6, profiles/r06_parity_budgets.txt).  fp64 needs NOTHING beyond the plain 1e-7 there (0 of 582,084 such
+# points on the twin, 0 of 1,372,812 on the MI355X) and gets nothing: round 5 held both dtypes to a flat 1e-2, and VERDICT
+# r5 showed every such result scaled by 1 + 5e-3 passing in fp64.
+ABSURD_FACTOR = 16.0
 DIRECT = [
     ("potential_temperature", ("t", "p"), {}),
     ("saturation_vapour_pressure", ("t",), {"phase": "mixed"}),
@@ -337,12 +362,24 @@ def _judge_direct(what, tag, in_dtype, got, want, ref64, f64, ins64):
         bar = np.maximum(tol, 4.0 * rel_err(w, ref64))
     # results beyond any thermodynamic quantity (theta_es of 1e24 K for a parcel at p < es(t), theta_w of -1e34 K from a
     # rational fit evaluated at theta_e/273.16 = 0.6): exponentials of 50-80, which multiply every rounding of their
-    # argument -- held to 1e-2 (and to the NaN / inf pattern), counted
+    # argument -- fp32: held to the exponent's own rounding (ABSURD_FACTOR above) and to the NaN / inf pattern; fp64: to the plain bar
     absurd = np.abs(w) > ABSURD
-    bar = np.where(absurd, np.maximum(bar, 1e-2), bar)
-    _record(what, "direct functions on the fuzz domain: results beyond 1e6 in SI units, held to 1e-2", int(absurd.sum()), r.size, r.size)
+    if tag == "f32":
+        with np.errstate(all="ignore"):
+            expo = np.where(absurd & np.isfinite(w), np.abs(np.log(np.abs(w))), 0.0)
+        absurd_bar = ABSURD_FACTOR * ES_UNITS[tag] * expo * UNIT[tag]
+        needed = absurd & (r > bar)  # beyond max(rtol, 4*delta): what the exponent's bar is there for
+        used_units = float((r[needed] / (expo[needed] * UNIT[tag])).max()) if needed.any() else 0.0
+        _record(what, "direct functions on the fuzz domain (fp32): results beyond 1e6 in SI units, rounding units of the exponent "
+                "needed (of ABSURD_FACTOR x ES_UNITS = 1600)", int(np.ceil(used_units)), ABSURD_FACTOR * ES_UNITS[tag], int(needed.sum()))
+        bar = np.where(absurd, np.maximum(bar, absurd_bar), bar)
+    else:
+        _record(what, "direct functions on the fuzz domain (fp64): results beyond 1e6 in SI units beyond the plain 1e-7 (no allowance)",
+                int((absurd & (r > bar)).sum()), 0, int(absurd.sum()))
     relaxed = int(((r > tol) & ~absurd).sum())
-    lim = max(3, 1e-2 * r.size)  # (saturated parcels at p < es(t): mixing ratios of 1-1e3 in exponents, the reference's fp32 run itself is off)
+    # (saturated parcels at p < es(t): mixing ratios of 1-1e3 in exponents, the reference's fp32 run itself is off; largest use
+    # on the MI355X 3.9e-4 of the points -- saturation_mixing_ratio_slope, water --, round 5 allowed 1e-2)
+    lim = max(3, 5e-4 * r.size)
     _record(what, "direct functions on the fuzz domain: points at max(rtol, 4*delta)", relaxed, lim, r.size)
     assert relaxed <= lim, f"{what}: {relaxed} points beyond {tol:g} (limit {lim:.0f})"
     # beyond max(rtol, 4*delta): the function's own conditioning must explain it -- ws = eps*es/(p - es) and its relatives
@@ -355,8 +392,8 @@ def _judge_direct(what, tag, in_dtype, got, want, ref64, f64, ins64):
         assert ok.all(), (f"{what}: rel err {r[idx][~ok].max():.3e} beyond max({tol:g}, 4*delta) and beyond {KAPPA_FACTOR:g} x kappa x unit at "
                           f"{idx[~ok][:4]}: got {g[idx][~ok][:4]} want {w[idx][~ok][:4]}")
         _record(what, "direct functions on the fuzz domain: beyond max(rtol, 4*delta), explained by the function's own amplification", int(idx.size),
-                max(3, 1e-3 * r.size), r.size)
-        assert idx.size <= max(3, 1e-3 * r.size), (what, int(idx.size))
+                max(3, 1e-4 * r.size), r.size)  # (largest use 20 of 262,144; round 5 allowed 1e-3)
+        assert idx.size <= max(3, 1e-4 * r.size), (what, int(idx.size))
     line = f"{what}: {r.size} points, worst {float(r[r <= tol].max()) if (r <= tol).any() else 0.0:.2e}, {relaxed} at 4*delta, inf-vs-huge {int(infmm.sum())}"
     CENSUS.append(line)
     return line

@@ -145,12 +145,13 @@ def test_cfg4_wet_bulb_newton_full_size_and_regime_boundaries(ek, field):
           f"{e['over_outside_band_1e6']}; ours beyond 1e-4 where the reference agrees with itself: "
           f"{e['over_and_reference_agrees_with_itself']}")
     _record("cfg4 full-size wet-bulb (levels 0-7)", "newton: points beyond 1e-4 of the fp32 reference (all inside the 1e-6 regime band)",
-            e["over"], max(4, 2 * e["reference_fp32_vs_fp64_over"] + 4), npts)
+            e["over"], 2 * e["reference_fp32_vs_fp64_over"], npts)
     assert e["nan_mismatch"] == 0
     assert e["over_outside_band_1e6"] == 0, "a point whose regime is well defined misses the 1e-4 bar"
     # where we miss, the reference's fp32 path itself disagrees with the fp64 reference about as often
-    assert e["over"] <= 2 * e["reference_fp32_vs_fp64_over"] + 4
-    assert e["over_vs_fp64_oracle"] <= 2 * e["reference_fp32_vs_fp64_over"] + 4
+    # (rounds 1-5 allowed four more than that; the use on the MI355X has been 0 of 51.84 M points in every round)
+    assert e["over"] <= 2 * e["reference_fp32_vs_fp64_over"]
+    assert e["over_vs_fp64_oracle"] <= 2 * e["reference_fp32_vs_fp64_over"]
     tw.free()
 
 

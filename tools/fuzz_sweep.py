@@ -31,7 +31,7 @@ def twin_sweep(a):
                 ins, kw = [d[k] for k in keys], dict(ept_method=method, t_method=tm)
                 os.environ.pop("EKM_TWIN_BISECT_EXACT", None)
                 got = twin.by_reference_name(func, ins, kw, dtype)
-                line = _fuzz.judge(func, keys, method, tm, tag, d, got, limits=a.adversarial != 2)
+                line = _fuzz.judge(func, keys, method, tm, tag, d, got, limits=a.adversarial != 2, sweep=True, min_identical=0.99 if a.adversarial else 0.999)
                 if tm == "bisect":
                     os.environ["EKM_TWIN_BISECT_EXACT"] = "1"
                     e = twin.by_reference_name(func, ins, kw, dtype)
@@ -71,7 +71,7 @@ def main():
                 out = getattr(ekm_hip.thermo, func)(*ins, ept_method=method, t_method=tm)
                 got = out.to_host()
                 out.free()
-                line = _fuzz.judge(func, keys, method, tm, tag, d, got, limits=a.adversarial != 2)
+                line = _fuzz.judge(func, keys, method, tm, tag, d, got, limits=a.adversarial != 2, sweep=True, min_identical=0.99 if a.adversarial else 0.999)
                 if tm == "bisect":
                     _ffi.check(lib.ekm_set_tuning_param(b"bisect_exact", 1))
                     ex = getattr(ekm_hip.thermo, func)(*ins, ept_method=method, t_method=tm)
