@@ -14,7 +14,10 @@ CPU so that PyTorch never touches the GPUs the HIP library is using.
 Rank 0 prints ONE JSON line: the contract fields plus `roofline` (algorithmic
 bytes / HIP-event kernel time against the 8 TB/s HBM peak), `cpu_baseline` (the
 NumPy oracle timed on this box's host cores on a bounded sample, N = 1 only) and
-`parity` (GPU output vs the oracle on points sampled from the timed arrays).
+`parity` (GPU output vs the oracle: the whole 8-level slab SURVEY.md 8d names, 51.84 M points of the timed arrays,
+through a pool of host processes, with the wet-bulb's regime-flip count; plus 256-point windows of 32 levels),
+`end_to_end` (H2D + kernel + D2H of that slab through the NumPy-in / NumPy-out path: PCIe-inclusive, never `value`) and,
+in `roofline`, the spread of the kernel time over three independently allocated buffer sets (`frac_min/median/max`).
 """
 import argparse
 import ctypes as C
@@ -102,6 +105,15 @@ def parse():
                          "report it as `sustained` (0 = skip); K timed steps stay what --steps asked for")
     ap.add_argument("--tiles", type=int, default=0)
     ap.add_argument("--unroll", type=int, default=0)
+    ap.add_argument("--parity-slab-levels", type=int, default=8,
+                    help="SURVEY.md 8d: levels (1800 x 3600 points each) of the timed arrays checked point by point against the "
+                         "oracle on a pool of host processes (N = 1; 0 = the 256-point windows only)")
+    ap.add_argument("--no-end-to-end", dest="end_to_end", action="store_false",
+                    help="skip `end_to_end` (H2D + kernel + D2H of the 8-level slab through the NumPy path, N = 1)")
+    ap.add_argument("--buffer-sets", type=int, default=3,
+                    help="independently allocated copies of the input/output fields the kernel is timed on (the first is the timed "
+                         "region's; the others add roofline.frac_min/median/max: where a 3.5-GB field lands in HBM moves a "
+                         "streaming kernel by 5-10 %%); N = 1, 1 = skip")
     return ap.parse_args()
 
 
@@ -207,7 +219,7 @@ class Dist:
             import torch.distributed as td
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("MASTER_PORT", "29533")  # (never reached under a launcher: torch.distributed.run always sets it)
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # single node: never depend on hostname resolution
             td.init_process_group("gloo", rank=self.rank, world_size=self.world,
                                   timeout=datetime.timedelta(seconds=600))
@@ -338,12 +350,21 @@ def build_inputs(args, sh, dev, nlev, np_dtype, seed):
     return t, q, p, plev, hyb
 
 
+def free_port():
+    """A TCP port nobody listens on right now (two benchmark runs on one node must not share a rendezvous port)."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # convenience: relaunch under torch.distributed.run as a child (nothing has touched the GPU yet)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT") or str(free_port()),
                os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
@@ -499,6 +520,14 @@ def main():
     # parity: rank 0 judges a sample of its own shard AND, at N > 1, a sample of the LAST rank's shard (whose first point is
     # not point 0 of the field), which travels through the gather together with the sample's place in the global field
     smp = None if args.dry_run else sample_shard(args, t, q, p, plev, outs, sh, nlev, np_dtype, hyb)
+    slab, e2e, sets = None, None, None
+    if not args.dry_run and dist.world == 1:
+        if args.parity_slab_levels > 0:
+            slab = slab_parity(args, t, q, p, plev, outs, nlev, np_dtype)
+        if args.buffer_sets > 1 and args.workload not in COLUMN_WORKLOADS:
+            sets = time_buffer_sets(args, sh, dev, nlev, np_dtype, seed, nout, entry, ints, my_ms)
+        if args.end_to_end:
+            e2e = end_to_end(args, t, q, p, plev, nlev, np_dtype)
     # The streaming reference of THIS launch on THESE buffers (the sample above is on the host by now: the outputs are
     # overwritten): the same input fields read and the same output fields written by a kernel that computes nothing
     # (ekm_stream_mix: the map kernels' launch shape, one add per stream).  The same kernel is 5-10 % faster or slower from
@@ -534,6 +563,9 @@ def main():
     parity_last, shard_window = None, None
     if not args.dry_run and dist.rank == 0:
         parity = judge_sample(args, smp)
+        if slab is not None:
+            # the slab is THE parity figure of the line; the windows (32 levels of the whole column) stay beside it
+            parity = dict(slab, windows=parity, ok=bool(slab["ok"] and parity["ok"])) if "points" in slab else dict(parity, slab=slab)
         if dist.world > 1:
             ls = last_smp[-1]
             parity_last = dict(judge_sample(args, ls), rank=dist.world - 1)
@@ -575,6 +607,14 @@ def main():
                     "kernel_ms_median": round(float(np.median(per_launch)), 4),
                     "kernel_ms_min": round(float(np.min(per_launch)), 4),
                     "hbm_achievable_gbs": HBM_ACHIEVABLE_GBS}
+            if sets:
+                # the same kernel on independently allocated copies of its fields, one process: `frac` above stays the timed
+                # region's (set 0); the spread is the placement lottery DESIGN.md section 3 describes, now in the record
+                ms_all = [kernel_ms] + sets["kernel_ms"]
+                fr = [bpp * n_local / (m * 1e-3) / 1e9 / HBM_PEAK_GBS for m in ms_all]
+                roof.update(buffer_sets=len(ms_all), kernel_ms_sets=[round(m, 4) for m in ms_all], frac_sets=[round(f, 4) for f in fr],
+                            frac_min=round(min(fr), 4), frac_median=round(float(np.median(fr)), 4), frac_max=round(max(fr), 4),
+                            buffer_sets_what=sets["what"])
             valu, why_not = None, "not collected (--valu none)"
             if args.valu == "measure" and dist.world == 1 and args.workload not in COLUMN_WORKLOADS:
                 valu, why_not = measure_valu(args, n_local)
@@ -627,7 +667,7 @@ def main():
                                    f" p as {dict(field='full field', level='137-level vector in LDS', hybrid='hybrid levels formed in-kernel from sp + A/B tables')[args.pmode]}",
                        "entry_point": f"ekm_{entry}_{args.dtype}", "points_per_gpu": n_total // dist.world, "p_mode": args.pmode,
                        "points_total": n_total, "shard_cut": sh["cut"], "per_rank": per_rank},
-            "roofline": roof, "sustained": sustained, "cpu_baseline": cpu, "parity": parity,
+            "roofline": roof, "sustained": sustained, "cpu_baseline": cpu, "parity": parity, "end_to_end": e2e,
             "parity_last_rank": parity_last, "shard_window_last_rank": shard_window,
             "hip_device_count": ndev_min, "devices_used": devices, "oversubscribed": oversub,
             # `value` = points x steps / timed_region; barrier_skew_ms = latest minus earliest start stamp of the ranks
@@ -644,6 +684,167 @@ def main():
             line["dry_run"] = True
         print(json.dumps(line), flush=True)
     dist.close()
+
+
+CENSUS_KIND = {"full": ("full", 5), "p3": ("p3", None), "wetbulb": ("wetbulb", 0), "wetbulb_bisect": ("bisect", None),
+               "wetbulb_bisect_bolton35": ("bisect:bolton35", None), "wetbulb_bisect_bolton39": ("bisect:bolton39", None)}
+NP_CALL = {"full": ("pipeline_full", {}), "p3": ("pipeline_svp_td_rh", {}),
+           "wetbulb": ("wet_bulb_temperature_from_specific_humidity", dict(ept_method="ifs", t_method="newton")),
+           "wetbulb_bisect": ("wet_bulb_temperature_from_specific_humidity", dict(ept_method="ifs", t_method="bisect")),
+           "wetbulb_bisect_bolton35": ("wet_bulb_temperature_from_specific_humidity", dict(ept_method="bolton35", t_method="bisect")),
+           "wetbulb_bisect_bolton39": ("wet_bulb_temperature_from_specific_humidity", dict(ept_method="bolton39", t_method="bisect")),
+           "rh": ("relative_humidity_from_specific_humidity", {}), "ept": ("ept_from_specific_humidity", dict(method="ifs"))}
+
+
+def slab_parity(args, t, q, p, plev, outs, nlev, np_dtype):
+    """every point of the first `--parity-slab-levels` levels of the TIMED arrays (8 x 1800 x 3600 = 51.84 M
+    points) against the oracle in the same dtype, on a pool of spawned host processes (oracle/census.py: they never touch
+    HIP; a level travels through one shared-memory file, nothing is pickled).  Per output: max relative error, points
+    beyond the bar, NaN-pattern mismatches; for the Newton wet-bulb the census of Davies-Jones regime ties (`regime_flips`:
+    points where the fp32 reference's own rounding took the other regime and the output under test sides with the fp64
+    reference); for the bisection the census in quanta.  Bounded like cpu_baseline: ~1 s of oracle time per level on 16 cores."""
+    from oracle import census
+
+    if args.workload not in CENSUS_KIND or args.pmode == "hybrid":
+        return {"skipped": f"no slab census for workload {args.workload} with p as {args.pmode} (windows only)"}
+    kind, tw_index = CENSUS_KIND[args.workload]
+    levels = list(range(min(args.parity_slab_levels, nlev)))
+    tol = 1e-4 if args.dtype == "f32" else 1e-6
+    pl = plev.to_host()
+
+    def fetch(lev, rows):
+        lo, hi = lev * INNER, (lev + 1) * INNER
+        rows[0] = t.flat_slice(lo, hi).to_host()
+        rows[1] = q.flat_slice(lo, hi).to_host()
+        rows[2] = p.flat_slice(lo, hi).to_host() if p is not None else pl[lev]
+        for k, o in enumerate(outs):
+            rows[3 + k] = o.flat_slice(lo, hi).to_host()
+
+    t0 = time.perf_counter()
+    total, _ = census.run_levels(fetch, levels, INNER, np_dtype, kind, len(outs), tw_index=tw_index, tol=tol)
+    res = {"points": len(levels) * INNER, "levels": [levels[0], levels[-1]], "tolerance": tol, "excluded_points": 0,
+           "seconds": round(time.perf_counter() - t0, 2),
+           "what": "every point of these levels of the timed arrays vs oracle/thermo_oracle.py in the same dtype (oracle/census.py)"}
+    if kind.startswith("bisect"):
+        b = total[0]
+        res.update(identical=b["identical"], one_quantum=b["one_quantum"], two_quanta=b["two_quanta"], more_than_two_quanta=b["more"],
+                   nan_mismatch=b["nan_mismatch"], differing_points_unanchored=b["differ_unanchored"],
+                   max_rel_err=b["max_quanta"] * 120.0 / 4096.0 / 250.0,
+                   ok=bool(b["more"] == 0 and b["differ_unanchored"] == 0 and b["identical"] >= 0.999 * b["n"]))
+        return res
+    res.update(max_rel_err=max(e["max_rel"] for e in total), max_rel_err_per_output=[float(f"{e['max_rel']:.3g}") for e in total],
+               over=sum(e["over"] for e in total), nan_mismatch=sum(e["nan_mismatch"] for e in total))
+    ok = res["nan_mismatch"] == 0
+    if tw_index is not None:
+        e = total[tw_index]
+        res.update(regime_flips=e["over_regime_flip_of_the_fp32_reference"], regime_boundary_points_1e5=e["band_1e5"],
+                   tw_over=e["over"], tw_over_outside_the_1e6_band=e["over_outside_band_1e6"], tw_over_unexplained=e["over_unexplained"],
+                   tw_over_vs_fp64_oracle=e["over_vs_fp64_oracle"], reference_fp32_vs_fp64_over=e["reference_fp32_vs_fp64_over"])
+        others = sum(x["over"] for k, x in enumerate(total) if k != tw_index)
+        # the bar of tests/test_gpu_configs.py: nothing outside the regime band misses, nothing unexplained, and inside the
+        # band no more misses than twice the reference's own fp32-vs-fp64 disagreements
+        ok = ok and others == 0 and e["over_outside_band_1e6"] == 0 and e["over_unexplained"] == 0 and \
+            e["over"] <= 2 * e["reference_fp32_vs_fp64_over"]
+    else:
+        ok = ok and res["over"] == 0
+    res["ok"] = bool(ok)
+    return res
+
+
+def end_to_end(args, t, q, p, plev, nlev, np_dtype):
+    """the 8-level slab through the NumPy-in / NumPy-out path -- pageable host arrays in, host arrays out --,
+    PCIe-inclusive; reported beside `value`, never as it.  `call_ms` is the call a user makes (best of 3; the library streams it
+    in slices, so the three phases overlap); h2d_ms / kernel_ms / d2h_ms are the same work done one phase at a time."""
+    import ekm_hip
+    from ekm_hip import thermo
+
+    if args.workload not in NP_CALL or args.pmode == "hybrid":
+        return None
+    name, kw = NP_CALL[args.workload]
+    fn = getattr(thermo, name)
+    L = min(8, nlev)
+    n = L * INNER
+    ht, hq = t.flat_slice(0, n).to_host().reshape(L, INNER), q.flat_slice(0, n).to_host().reshape(L, INNER)
+    hp = p.flat_slice(0, n).to_host().reshape(L, INNER) if p is not None else plev.to_host()[:L].reshape(L, 1)
+    ins = (ht, hq, hp)
+
+    def best(f, reps=3):
+        b, r = float("inf"), None
+        for _ in range(reps):
+            r = None  # the previous result is released outside the timed region
+            t0 = time.perf_counter()
+            r = f()
+            ekm_hip.synchronize()
+            b = min(b, time.perf_counter() - t0)
+        return b * 1e3, r
+
+    fn(*ins, **kw)  # warm: pinned pool, first-use tables
+    call_ms, res = best(lambda: fn(*ins, **kw))
+    nout = len(res) if isinstance(res, tuple) else 1
+    res = None
+    h2d_ms, dins = best(lambda: [ekm_hip.to_device(a) for a in ins])
+    kernel_ms, douts = best(lambda: fn(*dins, **kw), reps=5)
+    douts = list(douts) if isinstance(douts, tuple) else [douts]
+    d2h_ms, _ = best(lambda: [o.to_host() for o in douts])
+    for a in dins + douts:
+        a.free()
+    nbytes = sum(a.nbytes for a in ins) + nout * n * np.dtype(np_dtype).itemsize
+    return {"what": f"thermo.{name} on a {L}-level slab of the timed field, NumPy arrays in (pageable) and out, over PCIe",
+            "points": n, "arrays_in": len(ins), "arrays_out": nout, "bytes": int(nbytes),
+            "h2d_ms": round(h2d_ms, 3), "kernel_ms": round(kernel_ms, 3), "d2h_ms": round(d2h_ms, 3),
+            "phases_sum_ms": round(h2d_ms + kernel_ms + d2h_ms, 3), "call_ms": round(call_ms, 3),
+            "gbs": round(nbytes / (call_ms * 1e-3) / 1e9, 1), "points_per_s": n / (call_ms * 1e-3),
+            "note": "PCIe-inclusive; `value` is the HBM-resident rate (inputs already on the device when the timed region starts)"}
+
+
+def time_buffer_sets(args, sh, dev, nlev, np_dtype, seed, nout, entry, ints, my_ms):
+    """The timed kernel on `--buffer-sets` - 1 further, independently allocated copies of its input and output fields (same
+    generator, same seed: the same values at other addresses), 3 warm-up + min(steps, 20) launches each, HIP events."""
+    from ekm_hip import _ffi
+    from ekm_hip.device import DeviceArray
+
+    lib = _ffi.lib()
+    fn = getattr(lib, f"ekm_{entry}_{args.dtype}")
+    F = _ffi.Operand
+    itemsize = np.dtype(np_dtype).itemsize
+    out_ms = []
+    k_steps = max(1, min(args.steps, 20))
+    e0, e1, ms = C.c_void_p(), C.c_void_p(), C.c_float()
+    _ffi.check(lib.ekm_event_create(dev, C.byref(e0)))
+    _ffi.check(lib.ekm_event_create(dev, C.byref(e1)))
+    # the sets are allocated one after the other and ALL kept until the end, so that no set reuses the blocks of another
+    keep = []
+    for _ in range(args.buffer_sets - 1):
+        t, q, p, plev, hyb = build_inputs(args, sh, dev, nlev, np_dtype, seed)
+        outs = [DeviceArray.empty((sh["n_local"],), np_dtype, dev) for _ in range(nout)]
+        keep.append((t, q, p, plev, hyb, outs))
+        op_t, op_q = F(t.ptr, _ffi.FIELD, 0, 0, 0), F(q.ptr, _ffi.FIELD, 0, 0, 0)
+        if p is not None:
+            op_p = F(p.ptr, _ffi.FIELD, 0, 0, 0)
+        elif args.pmode == "hybrid":
+            nz = np.flatnonzero(hyb["Bh"] != 0.0)
+            nflat = int(max(0, (nz[0] if nz.size else hyb["Bh"].size) - 1))
+            op_p = F(hyb["sp"].ptr, _ffi.HYBRID_FULL, nflat, sh["lev1"] - sh["lev0"], sh["col1"] - sh["col0"], hyb["A"].ptr, hyb["B"].ptr)
+        else:
+            op_p = F(plev.ptr + sh["lev0"] * itemsize, _ffi.LEVEL_MAJOR, 0, sh["lev1"] - sh["lev0"], INNER)
+        operands = {"potential_temperature": (op_t, op_p), "saturation_vapour_pressure": (op_t,)}.get(entry, (op_t, op_q, op_p))
+        cargs = [dev, None] + [C.byref(o) for o in operands] + list(ints) + [o.ptr for o in outs] + [sh["n_local"]]
+        for _ in range(3):
+            _ffi.check(fn(*cargs))
+        _ffi.check(lib.ekm_event_record(dev, e0, None))
+        for _ in range(k_steps):
+            _ffi.check(fn(*cargs))
+        _ffi.check(lib.ekm_event_record(dev, e1, None))
+        _ffi.check(lib.ekm_sync(dev))
+        _ffi.check(lib.ekm_event_elapsed_ms(dev, e0, e1, C.byref(ms)))
+        out_ms.append(ms.value / k_steps)
+    for t, q, p, plev, hyb, outs in keep:
+        for a in [t, q, p, plev] + outs + ([hyb["A"], hyb["B"], hyb["sp"]] if hyb else []):
+            if a is not None:
+                a.free()
+    return {"kernel_ms": out_ms,
+            "what": f"set 0 = the timed region's arrays ({args.steps} launches); sets 1.. = fresh allocations of every field, same "
+                    f"values, 3 warm-up + {k_steps} launches each, HIP events, same process"}
 
 
 def sample_shard(args, t, q, p, plev, outs, sh, nlev, np_dtype, hyb=None):
@@ -779,7 +980,8 @@ def valu_from_profiles(args, why=""):
 
 def _child_cmd(args, steps, warm):
     return [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warm), "--no-cpu-baseline",
-            "--traffic", "none", "--valu", "none", "--sustain", "0", "--no-stream-ceiling", "--workload", args.workload, "--pmode", args.pmode,
+            "--traffic", "none", "--valu", "none", "--sustain", "0", "--no-stream-ceiling", "--parity-slab-levels", "0", "--no-end-to-end",
+            "--buffer-sets", "1", "--workload", args.workload, "--pmode", args.pmode,
             "--dtype", args.dtype, "--levels", str(args.levels)]
 
 

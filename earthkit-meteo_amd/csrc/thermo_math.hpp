@@ -883,14 +883,26 @@ constexpr double kHeapTau0 = 2.5e-6, kHeapTau1 = 1.2e-6;
 #define EKM_HEAP_B128 1    // 1: the record in one ds_read_b128; 0: ds_read_b64 + ds_read_b32 from the one address (A/B:
 #endif                     // 3.32 against 3.21 ms; merged by the compiler into ONE ds_read_b96 when L sits right behind a: 3.73)
 #ifndef EKM_HEAP_L_SLOT
-#define EKM_HEAP_L_SLOT 3  // record = (es, a, t_m, L)
+#define EKM_HEAP_L_SLOT 3  // record = (es, a, b, L)
+#endif
+// The fourth float of the 16-byte record: b_m = kHeapTau1*|a_m|, the node's own share of the tolerance band.  With it the
+// band of a step is ONE fma on values the step has anyway, b_m + (kHeapTau0/eps)*w_m  (w_m = p + (eps - 1)*es_m >= eps*p
+// wherever es_m <= p; a node with es_m > p is inside the NaN rule whatever its test says), instead of a product
+// kHeapTau0*p -- recomputed at every step for want of a register at the 64-VGPR cap -- and an fma: 8 -> 7 vector
+// instructions per step and point (profiles/r06_tree_walk.txt).  0: round 5's band, kHeapTau1*|a_m| + kHeapTau0*p.
+#ifndef EKM_HEAP_BAND_SLOT
+#define EKM_HEAP_BAND_SLOT 1
+#endif
+// A/B only (per-depth attribution of LDS conflict cycles, tools/pmc_bisect_depth.sh): the walk stops after this many steps
+#ifndef EKM_WALK_DEPTH
+#define EKM_WALK_DEPTH 12
 #endif
 template <int METHOD, class T>
 constexpr int heap_rec() {
   return (METHOD == EPT_IFS && sizeof(T) == 4) ? EKM_HEAP_REC_IFS : 3;
 }
 struct HeapNode {
-  float es, a, L;
+  float es, a, L, b;  // b: the record's fourth float (16-byte records only), else 0
 };
 template <int REC>
 EKM_HD HeapNode heap_read(const float* __restrict__ tab, unsigned node) {
@@ -904,6 +916,7 @@ EKM_HD HeapNode heap_read(const float* __restrict__ tab, unsigned node) {
     r.es = v[0];
     r.a = v[1];
     r.L = v[EKM_HEAP_L_SLOT];
+    r.b = v[5 - EKM_HEAP_L_SLOT];
 #else
     typedef float f2 __attribute__((ext_vector_type(2)));
     const char* __restrict__ rec = base + (node << 4);  // ONE address: ds_read_b64 + ds_read_b32 offset:12
@@ -911,6 +924,7 @@ EKM_HD HeapNode heap_read(const float* __restrict__ tab, unsigned node) {
     r.es = ea[0];
     r.a = ea[1];
     r.L = *reinterpret_cast<const float*>(rec + 4 * EKM_HEAP_L_SLOT);
+    r.b = EKM_HEAP_BAND_SLOT ? *reinterpret_cast<const float*>(rec + 4 * (5 - EKM_HEAP_L_SLOT)) : 0.0f;
 #endif
   } else {
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -918,16 +932,19 @@ EKM_HD HeapNode heap_read(const float* __restrict__ tab, unsigned node) {
     r.es = ea[0];
     r.a = ea[1];
     r.L = *reinterpret_cast<const float*>(base + 8 * kHeapNodes + (node << 2));
+    r.b = 0.0f;
   }
 #else
   if (REC == 4) {
     r.es = tab[4 * node];
     r.a = tab[4 * node + 1];
     r.L = tab[4 * node + EKM_HEAP_L_SLOT];
+    r.b = tab[4 * node + (5 - EKM_HEAP_L_SLOT)];
   } else {
     r.es = tab[2 * node];
     r.a = tab[2 * node + 1];
     r.L = tab[2 * kHeapNodes + node];
+    r.b = 0.0f;
   }
 #endif
   return r;
@@ -967,7 +984,7 @@ EKM_HD void bisect_heap_fill(float* __restrict__ tab, int i) {
     tab[4 * i] = es;
     tab[4 * i + 1] = a;
     tab[4 * i + EKM_HEAP_L_SLOT] = L;
-    tab[4 * i + (5 - EKM_HEAP_L_SLOT)] = t;
+    tab[4 * i + (5 - EKM_HEAP_L_SLOT)] = EKM_HEAP_BAND_SLOT ? float(kHeapTau1) * __builtin_fabsf(a) : t;
   } else {
     tab[2 * i] = es;
     tab[2 * i + 1] = a;
@@ -1037,8 +1054,8 @@ EKM_HD float bisect_exact_residual(float es, float a, float w, float te, float t
 }
 
 // WS: test ws >= kB35WsExact at every node (A/B only: both walks ask once, of the hottest node they visited)
-template <int METHOD, bool WS = false, bool F64 = false>
-EKM_HD float bisect_fast_test(float es, float a, float u, float p, float kl, float& w, float thr0, bool& amb) {
+template <int METHOD, bool WS = false, bool F64 = false, bool BAND_SLOT = false>
+EKM_HD float bisect_fast_test(float es, float a, float u, float p, float kl, float& w, float thr0, bool& amb, float b = 0.0f) {
   float D, scale;  // D: MINUS the quantity of the comments above (bisect_heap_child takes it so); scale: |a_m| resp. its
   bool big_ws = false;  // counterpart -- the part of the band that goes with the size of the exponent
   if (METHOD == EPT_IFS) {
@@ -1069,7 +1086,10 @@ EKM_HD float bisect_fast_test(float es, float a, float u, float p, float kl, flo
     // more than the band above knows of -- dD = dw*(2*w*|X| + kappa/ln2*w + |a|*eps*es)
     if (F64) thr0 = m_fma(1.5e-7f * p, m_fma(w, m_fma(2.0f, __builtin_fabsf(X), 0.5f), __builtin_fabsf(aees)), thr0);
   }
-  amb = !(__builtin_fabsf(D) > m_fma(__builtin_fabsf(scale), float(METHOD == EPT_IFS ? kHeapTau1 : 2.0 * kHeapTau1), thr0));  // NaN: ambiguous
+  if (METHOD == EPT_IFS && BAND_SLOT)  // b = kHeapTau1*|a_m| from the record; (kHeapTau0/eps)*w >= kHeapTau0*p (EKM_HEAP_BAND_SLOT)
+    amb = !(__builtin_fabsf(D) > m_fma(w, float(kHeapTau0 / k::eps), b));
+  else
+    amb = !(__builtin_fabsf(D) > m_fma(__builtin_fabsf(scale), float(METHOD == EPT_IFS ? kHeapTau1 : 2.0 * kHeapTau1), thr0));  // NaN: ambiguous
   if (METHOD == EPT_BOLTON35 && WS) amb = amb || big_ws;
   return D;
 }
@@ -1125,9 +1145,10 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
     tfix[j] = 0.0f;
   }
   constexpr int REC = heap_rec<METHOD, float>();
+  constexpr bool BAND_SLOT = METHOD == EPT_IFS && REC == 4 && EKM_HEAP_BAND_SLOT;
 #pragma unroll
-  for (int d = 0; d < 12; ++d) {
-    float es[V], a[V], w[V], D[V], L[V];
+  for (int d = 0; d < EKM_WALK_DEPTH; ++d) {
+    float es[V], a[V], w[V], D[V], L[V], b[V];
     bool amb[V];
     unsigned long long any = 0ull;  // lanes of the wave with an ambiguous test at this depth, over the V points
     // (forcing all table reads of a step out before the first is waited for -- the compiler pairs the points, two LDS
@@ -1138,11 +1159,12 @@ EKM_HD void t_on_ma_bisect_heap(const float (&lte)[V], const float (&te)[V], con
       es[j] = nd.es;
       a[j] = nd.a;
       L[j] = nd.L;
+      b[j] = nd.b;
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       const float u = L[j] - lq[j];
-      D[j] = bisect_fast_test<METHOD, false>(es[j], a[j], u, p[j], kl[j], w[j], thr0[j], amb[j]);
+      D[j] = bisect_fast_test<METHOD, false, false, BAND_SLOT>(es[j], a[j], u, p[j], kl[j], w[j], thr0[j], amb[j], b[j]);
       any |= EKM_WAVE_MASK(amb[j]);
       amb[j] = amb[j] || all_exact;
     }

@@ -317,7 +317,13 @@ def _as_the_reference_types_them(name, ints, args, outs):
 # the call is then a call on DeviceArrays, which has a recipe.  Only where that changes nothing: every array operand a
 # DeviceArray of ONE dtype on ONE device (a Python scalar is weak: the arrays' dtype wins, as in the reference), not while
 # recording (there the fill is a node of the graph and the value a constant of it), not inside multi_gpu().
-_scalar_cache = {}
+# One 0-d device array per (device, STREAM, dtype, bit pattern): a cached scalar is only ever read by kernels of the stream
+# that wrote it, so when an entry is dropped its block goes back to that stream's block cache and any reuse is ordered
+# behind those kernels (shared across streams -- rounds 4-5 -- a block re-filed under the last toucher's stream could be
+# overwritten while a kernel on another stream still read it: ADVICE r5).  Least recently used entries go first.
+import collections as _collections
+
+_scalar_cache = _collections.OrderedDict()
 _SCALARS_MAX = 256
 
 
@@ -342,13 +348,15 @@ def _scalars_on_device(args):
             out.append(a)
             continue
         bits = np.asarray(a, dtype=dt).tobytes()
-        key = (dev, dt.char, bits)
+        stream = current_stream()
+        key = (dev, stream, dt.char, bits)
         d = _scalar_cache.get(key)
-        if d is None:
-            if len(_scalar_cache) >= _SCALARS_MAX:
-                _scalar_cache.clear()
+        if d is not None:
+            _scalar_cache.move_to_end(key)
+        else:
+            while len(_scalar_cache) >= _SCALARS_MAX:
+                _scalar_cache.popitem(last=False)
             d = DeviceArray.empty((), dt, dev)
-            stream = current_stream()
             words = np.frombuffer(bits, dtype=np.uint32)
             base = d.on(stream)
             for w in range(words.size):
@@ -597,10 +605,12 @@ def _run_single(name, args, ints=(), eps=None, dtype=None, host_out=None, touche
     return _collect(_submit(name, args, ints, eps, dtype, host_out, toucher))
 
 
-def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=None, reserve_rows=None):
+def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=None, reserve_rows=None, uploaded=None):
     """Upload what lives on the host, launch, return without waiting for the kernel (the uploads themselves are
     synchronous copies on the current stream).  `reserve_rows` = (rows of this slice, rows of the longest slice):
-    field-sized device blocks are reserved at the longest slice's size (streamed path)."""
+    field-sized device blocks are reserved at the longest slice's size (streamed path).  `uploaded`: an event handle
+    recorded on the stream behind the last upload and BEFORE the launch (the streamed path waits for a slice's uploads,
+    not for its kernel)."""
     ins, outs, int_names, has_eps = OPS[name]
     assert len(args) == len(ins) and len(ints) == len(int_names)
     plan = _Plan(args, dtype)
@@ -689,6 +699,8 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
     if has_eps:
         cargs.append(float(eps))
     cargs += [r.ptr for r in results] + [plan.n]
+    if uploaded is not None:
+        _ffi.check(lib.ekm_event_record(dev, uploaded, stream))
     _ffi.check(fn(*cargs))
     if (not temps and plan.on_device and not plan.hybrid and dtype is None and host_out is None and reserve_rows is None
             and plan.n and len(_recipes) < _RECIPES_MAX and all(type(a) is DeviceArray for a in args)):

@@ -44,6 +44,21 @@ def _lane_stream(dev, slot):
         return _streams[k]
 
 
+_events = {}  # (device, lane slot) -> event recorded behind a slice's uploads (one per lane: the uploader waits for it each time)
+
+
+def _uploaded_event(dev, slot):
+    import ctypes as C
+
+    with _streams_lock:
+        k = (dev, slot)
+        if k not in _events:
+            ev = C.c_void_p()
+            _ffi.check(_ffi.lib().ekm_event_create(dev, C.byref(ev)))
+            _events[k] = ev
+        return _events[k]
+
+
 def release_streams():
     """Destroy the lane streams of the streamed NumPy path (and return their cached blocks to HIP)."""
     from .device import stream_destroy
@@ -51,6 +66,10 @@ def release_streams():
     with _streams_lock:
         items = list(_streams.items())
         _streams.clear()
+        events = list(_events.items())
+        _events.clear()
+    for (dev, _slot), ev in events:
+        _ffi.lib().ekm_event_destroy(dev, ev)
     for (dev, _slot), st in items:
         stream_destroy(st, dev)
 
@@ -201,10 +220,15 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
                 part = [h[lo:hi] if sp else a for h, a, sp in zip(host, args, spans)]
                 # slices differ by one row: every slice's device blocks are sized for the LONGEST slice, so a lane takes
                 # back exactly the blocks it released (same bucket) and the footprint stays lanes x slice, live + cached
-                pend = _submit(name, part, ints, eps, dtype, host_out=[o[lo:hi] for o in outs], reserve_rows=(hi - lo, most))
+                ev = _uploaded_event(dev, k % depth)
+                pend = _submit(name, part, ints, eps, dtype, host_out=[o[lo:hi] for o in outs], reserve_rows=(hi - lo, most),
+                               uploaded=ev)
                 # ONE slice's uploads in flight: from pinned inputs they are asynchronous, and the uploads of several lanes
-                # queued at once share the link badly (P3 from pinned inputs: 60 GB/s against 77 with this wait)
-                _ffi.check(_ffi.lib().ekm_stream_sync(dev, pend.stream))
+                # queued at once share the link badly (P3 from pinned inputs: 60 GB/s against 77 with this wait).  The wait
+                # is for the UPLOADS (an event recorded behind the last one, before the launch), not for the slice's kernel:
+                # upload k+1 runs under kernel k (rounds 4-5 waited for the whole stream, which put a compute-heavy kernel --
+                # the bisection wet-bulb, fp64 P5 -- in series with the uploads: ADVICE r5)
+                _ffi.check(_ffi.lib().ekm_event_sync(dev, ev))
                 handoff.put(((lo, hi), pend))
                 if trace is not None:
                     trace.append(("up", k, t0, t1, _time.perf_counter()))

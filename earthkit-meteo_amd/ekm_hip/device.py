@@ -103,6 +103,10 @@ def stream_destroy(stream, dev=None):
     dev = current_device() if dev is None else dev
     lib = _ffi.lib()
     _ffi.check(lib.ekm_stream_sync(dev, stream))
+    from . import _engine  # (imports this module: late)
+
+    for key in [k for k in list(_engine._scalar_cache) if k[0] == dev and k[1] == stream]:  # the scalars remembered for this stream
+        _engine._scalar_cache.pop(key, None)
     # Arrays computed on this stream outlive it ("compute on a temporary stream, destroy it, keep the results"):
     # all their work is complete now, so they are re-filed under the default stream -- a later use on any stream
     # must not record an event on the destroyed handle.
@@ -517,23 +521,66 @@ class _PinnedPool:
     Page-locked memory cannot be swapped and counts against container / memlock limits, so the pool is BOUNDED, and its
     bound comes from the machine (round 4's constant 2 GiB sent the 5 GB of results of a 32-level six-output call to
     pageable arrays: 54 GB/s instead of 70): blocks held by callers plus blocks cached never exceed
-    EKM_PINNED_CACHE_BYTES -- default min(25 % of MemAvailable when the package is imported, 16 GiB) -- in total; a result
+    EKM_PINNED_CACHE_BYTES -- default min(25 % of MemAvailable, 25 % of the memory cgroup's headroom, a deliberate
+    RLIMIT_MEMLOCK, 16 GiB), read when the package is imported -- in total; a result
     that does not fit (after cached blocks of other sizes have been let go) is an ordinary pageable array, and so is any
     result once the callers hold EKM_PINNED_LIVE_BYTES (default: the same number) alive (`ekm_hip.empty_cache()` frees
     the cached blocks).  `ekm_hip.memory_stats()["pinned"]` reports both and what is in use.  An array in
     pooled memory does not own its data: `.base` is a ctypes buffer and `ndarray.resize` refuses."""
 
     @staticmethod
+    def _cgroup_headroom(root="/sys/fs/cgroup"):
+        """Bytes this process's memory cgroup still allows (limit - current use), or None when there is no finite limit.
+        Page-locked memory is charged to the cgroup and cannot be reclaimed: beyond it the kernel kills the process
+        instead of failing hipHostMalloc."""
+        best = None
+        for lim, cur in ((f"{root}/memory.max", f"{root}/memory.current"),                                       # cgroup v2
+                         (f"{root}/memory/memory.limit_in_bytes", f"{root}/memory/memory.usage_in_bytes")):      # v1
+            try:
+                with open(lim) as f:
+                    txt = f.read().strip()
+                if txt == "max":
+                    continue
+                limit = int(txt)
+                if limit <= 0 or limit >= 1 << 60:  # v1 reports "unlimited" as a huge number
+                    continue
+                with open(cur) as f:
+                    used = int(f.read().strip())
+                room = max(0, limit - used)
+                best = room if best is None else min(best, room)
+            except (OSError, ValueError):
+                continue
+        return best
+
+    @staticmethod
     def machine_limit():
-        """min(25 % of MemAvailable, 16 GiB); 2 GiB when /proc/meminfo cannot be read."""
+        """min(25 % of MemAvailable, 25 % of the memory cgroup's headroom, RLIMIT_MEMLOCK when finite, 16 GiB); 2 GiB when
+        /proc/meminfo cannot be read.  MemAvailable alone is host-wide: in a container whose cgroup allows less, a pool
+        sized from it would be killed by the kernel, not refused by hipHostMalloc."""
+        limit = 2 << 30
         try:
             with open("/proc/meminfo") as f:
                 for ln in f:
                     if ln.startswith("MemAvailable:"):
-                        return int(min(int(ln.split()[1]) * 1024 // 4, 16 << 30))
+                        limit = int(min(int(ln.split()[1]) * 1024 // 4, 16 << 30))
+                        break
         except (OSError, ValueError, IndexError):
             pass
-        return 2 << 30
+        room = _PinnedPool._cgroup_headroom()
+        if room is not None:
+            limit = min(limit, room // 4)
+        try:
+            import resource
+
+            soft, _ = resource.getrlimit(resource.RLIMIT_MEMLOCK)
+            # (the ROCm runtime pins through the kernel driver, which does not count against RLIMIT_MEMLOCK on every
+            # kernel; where the limit is finite and tiny -- 64 KiB / 8 MiB defaults -- it says nothing about the driver's
+            # pinning and is ignored, a deliberate limit of 256 MiB or more is honoured)
+            if soft != resource.RLIM_INFINITY and soft >= 256 << 20:
+                limit = min(limit, int(soft))
+        except (ImportError, OSError, ValueError):
+            pass
+        return int(max(limit, 0))
 
     def __init__(self):
         self.free = {}    # bucket -> [ptr, ...]
@@ -587,6 +634,8 @@ class _PinnedPool:
                 self.cached -= b
                 self.handed_out += b
                 return lst.pop(), b
+            if self.handed_out + b > self.limit:
+                return None, b  # no eviction can make it fit: keep the cache (blocks of the other sizes are re-pinned slowly)
             evicted = self._evict_locked(b, keep=None)
             fits = self.handed_out + self.cached + b <= self.limit
             if fits:

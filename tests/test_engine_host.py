@@ -260,3 +260,40 @@ def test_the_typing_table_regenerates_from_the_reference(tmp_path):
     out = tmp_path / "rules.py"
     subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "gen_dtype_rules.py"), str(out)], check=True, capture_output=True, timeout=600)
     assert out.read_text() == open(os.path.join(root, "earthkit-meteo_amd", "ekm_hip", "_dtype_rules.py")).read()
+
+
+def test_pinned_pool_bound_follows_the_memory_cgroup(tmp_path):
+    """MemAvailable is host-wide; page-locked memory is charged to the container's cgroup and cannot be
+    reclaimed, so the pool's default bound is clamped by the cgroup's headroom (v2 memory.max, v1 memory.limit_in_bytes)."""
+    from ekm_hip.device import _PinnedPool
+
+    assert _PinnedPool._cgroup_headroom(str(tmp_path)) is None  # no controller files: no finite limit
+    (tmp_path / "memory.max").write_text("max\n")
+    (tmp_path / "memory.current").write_text("123\n")
+    assert _PinnedPool._cgroup_headroom(str(tmp_path)) is None
+    (tmp_path / "memory.max").write_text(f"{8 << 30}\n")
+    (tmp_path / "memory.current").write_text(f"{3 << 30}\n")
+    assert _PinnedPool._cgroup_headroom(str(tmp_path)) == 5 << 30
+    (tmp_path / "memory").mkdir()
+    (tmp_path / "memory" / "memory.limit_in_bytes").write_text("9223372036854771712\n")  # v1's "unlimited"
+    (tmp_path / "memory" / "memory.usage_in_bytes").write_text("1\n")
+    assert _PinnedPool._cgroup_headroom(str(tmp_path)) == 5 << 30
+    (tmp_path / "memory" / "memory.limit_in_bytes").write_text(f"{4 << 30}\n")
+    (tmp_path / "memory" / "memory.usage_in_bytes").write_text(f"{1 << 30}\n")
+    assert _PinnedPool._cgroup_headroom(str(tmp_path)) == 3 << 30
+    assert 0 <= _PinnedPool.machine_limit() <= 16 << 30
+
+
+def test_pinned_pool_does_not_flush_its_cache_for_a_request_that_cannot_fit():
+    """take() used to evict every cached block of the other sizes before noticing that the request could not fit
+    beside what the callers hold."""
+    from ekm_hip.device import _PinnedPool
+
+    pool = _PinnedPool()
+    pool.limit = pool.live_limit = 64 << 20
+    pool.free = {8 << 20: [0xdead0000]}      # one cached 8-MiB block (never dereferenced: nothing below allocates or frees)
+    pool.cached = 8 << 20
+    pool.handed_out = 40 << 20               # the callers hold 40 MiB
+    ptr, b = pool.take(32 << 20)             # 40 + 32 > 64: cannot fit whatever is evicted
+    assert ptr is None and b == 32 << 20
+    assert pool.cached == 8 << 20 and pool.free[8 << 20] == [0xdead0000]

@@ -524,15 +524,16 @@ def _csv_wet_bulb_check(got, want, t_method, what):
     allclose(rtol=1e-3, atol=0, equal_nan=True).  Newton and direct: exactly that.  Bisection: on the exactly
     saturated low-pressure rows of that table the sign of a mathematically zero residual decides between a
     number and NaN (the reference's own fp32 and fp64 outputs differ there), so NaN-pattern differences are
-    counted against a budget of 2 % of the rows (largest seen: recorded by the ledger) instead of 0."""
+    counted against a budget of 0.5 % of the rows = 2 of 480 (largest seen on the MI355X: 1 row, rounds 2-6; rounds 2-5 allowed 2 %)
+    instead of 0."""
     from _compare import _record
 
     if t_method != "bisect":
         assert np.allclose(got, want, rtol=1e-3, atol=0, equal_nan=True), what
         return
     mism = np.isfinite(got) != np.isfinite(want)
-    _record(what, "bisect (reference CSV): NaN-pattern differences on saturated rows", mism.sum(), 0.02 * mism.size, mism.size)
-    assert mism.sum() <= 0.02 * mism.size, f"{what}: {mism.sum()} NaN-pattern differences"
+    _record(what, "bisect (reference CSV): NaN-pattern differences on saturated rows", mism.sum(), int(0.005 * mism.size), mism.size)
+    assert mism.sum() <= int(0.005 * mism.size), f"{what}: {mism.sum()} NaN-pattern differences"
     ok = ~mism
     assert np.allclose(got[ok], want[ok], rtol=1e-3, atol=0, equal_nan=True), what
 

@@ -213,7 +213,7 @@ def test_a_python_scalar_beside_device_arrays_is_uploaded_once(rec, monkeypatch)
     from ekm_hip import _engine
 
     monkeypatch.setattr(_engine, "_recipes", {})
-    monkeypatch.setattr(_engine, "_scalar_cache", {})
+    monkeypatch.setattr(_engine, "_scalar_cache", type(_engine._scalar_cache)())
     t = ekm_hip.DeviceArray.empty((30, 64), np.float32)
     rec.calls.clear()
     a = ekm_hip.thermo.potential_temperature(t, 85000.0)

@@ -56,6 +56,26 @@ def adversarial_args(func, argnames):
         cols = [_typical(nm, nodd * base, rng) for nm in argnames]
         cols[a] = np.repeat(ODD, base)
         blocks.append(cols)
+    # NaN in each operand in turn BESIDE an IEEE special (or any other odd value) in each of the others (the rule
+    # that a NaN input explains a non-finite fast-pass output, ops.hpp::two_pass_redo_needed / OpDeps, must not leave the fast
+    # pass's NaN standing where the formula ignores that operand and the plain pass returns a number or an infinity)
+    if narg >= 2:
+        import itertools
+
+        for a in range(narg):
+            others = [i for i in range(narg) if i != a]
+            combos = np.array(list(itertools.product(ODD, repeat=len(others))) if len(others) <= 2 else
+                              [c for c in itertools.product(ODD[[0, 2, 3, 4, 5, 10, 20]], repeat=len(others))])
+            cols = [None] * narg
+            cols[a] = np.full(len(combos), np.nan)
+            for j, i in enumerate(others):
+                cols[i] = combos[:, j].copy()
+            blocks.append(cols)
+            for i in others:  # ... and beside ONE special, the rest ordinary
+                cols = [_typical(nm, nodd, rng) for nm in argnames]
+                cols[a] = np.full(nodd, np.nan)
+                cols[i] = ODD.copy()
+                blocks.append(cols)
     cols = [_typical(nm, 4096, rng) for nm in argnames]  # several at once
     for c in cols:
         idx = rng.random(c.size) < 0.4

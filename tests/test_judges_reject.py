@@ -42,9 +42,15 @@ def points(request):
 
 
 def _rejects(judge, got, what):
-    with pytest.raises(AssertionError):
-        judge(got)
-        pytest.fail(f"the judge ACCEPTED {what}", pytrace=False)
+    from _compare import CENSUS, LEDGER
+
+    marks = len(LEDGER), len(CENSUS)
+    try:
+        with pytest.raises(AssertionError):
+            judge(got)
+            pytest.fail(f"the judge ACCEPTED {what}", pytrace=False)
+    finally:  # what a deliberately wrong output "used" is not part of the run's budget ledger
+        del LEDGER[marks[0]:], CENSUS[marks[1]:]
 
 
 def _pick(rng, mask, k):
