@@ -1,6 +1,6 @@
 // Per-grid-point thermodynamics, templated on the real type (float / double).
 //
-// One statement of the arithmetic for both the gfx950 kernels (kernels_*.hip)
+// One statement of the arithmetic for both the gfx950 kernels (gen/entries_*.hip)
 // and the host test twin (host_twin.cpp, test infrastructure only).  Every
 // function cites the reference lines it restates:
 //   thermo.py:N  = /root/reference/src/earthkit/meteo/thermo/array/thermo.py:N
@@ -885,13 +885,15 @@ constexpr double kHeapTau0 = 2.5e-6, kHeapTau1 = 1.2e-6;
 #ifndef EKM_HEAP_L_SLOT
 #define EKM_HEAP_L_SLOT 3  // record = (es, a, b, L)
 #endif
-// The fourth float of the 16-byte record: b_m = kHeapTau1*|a_m|, the node's own share of the tolerance band.  With it the
-// band of a step is ONE fma on values the step has anyway, b_m + (kHeapTau0/eps)*w_m  (w_m = p + (eps - 1)*es_m >= eps*p
-// wherever es_m <= p; a node with es_m > p is inside the NaN rule whatever its test says), instead of a product
-// kHeapTau0*p -- recomputed at every step for want of a register at the 64-VGPR cap -- and an fma: 8 -> 7 vector
-// instructions per step and point (profiles/r06_tree_walk.txt).  0: round 5's band, kHeapTau1*|a_m| + kHeapTau0*p.
+// A/B (round 6, NEGATIVE: 3.07 against 3.02 ms): the fourth float of the 16-byte record as b_m = kHeapTau1*|a_m|, the node's own
+// share of the tolerance band, so that the band of a step is ONE fma on values the step has anyway, b_m + (kHeapTau0/eps)*
+// w_m  (w_m = p + (eps - 1)*es_m >= eps*p wherever es_m <= p), instead of the product kHeapTau0*p -- recomputed at every
+// step for want of a register at the 64-VGPR cap -- and an fma: 8 -> 7 vector instructions per step and point in the
+// static code, but the band is 1/eps = 1.6 x wider in its pressure part, the exact branch is entered that much more
+// often, and the EXECUTED count went up, 130.9 -> 139.1 per point (profiles/r06_tree_walk.txt).  0 (default): round 5's
+// band, kHeapTau1*|a_m| + kHeapTau0*p, and the slot holds t_m.
 #ifndef EKM_HEAP_BAND_SLOT
-#define EKM_HEAP_BAND_SLOT 1
+#define EKM_HEAP_BAND_SLOT 0
 #endif
 // A/B only (per-depth attribution of LDS conflict cycles, tools/pmc_bisect_depth.sh): the walk stops after this many steps
 #ifndef EKM_WALK_DEPTH
@@ -904,9 +906,25 @@ constexpr int heap_rec() {
 struct HeapNode {
   float es, a, L, b;  // b: the record's fourth float (16-byte records only), else 0
 };
+// A/B only (profiles/r06_tree_walk.txt): the records of depths >= 8 -- where the LDS bank conflicts
+// are, 96 % of them in the last four steps -- stored at idx ^ ((idx >> 4) & 15), so that nodes 16 apart stop sharing the
+// banks of a 16-byte slot.  The collisions there are random (a wave's lanes scatter over hundreds of leaves of the noisy
+// benchmark field), a permutation of the slots cannot change their statistics, and the three extra instructions per deep
+// step cost more than nothing: 0 (default) = plain heap order.
+#ifndef EKM_HEAP_SWIZZLE
+#define EKM_HEAP_SWIZZLE 0
+#endif
+EKM_HD unsigned heap_slot(unsigned node) {
+#if EKM_HEAP_SWIZZLE
+  return node >= 256u ? node ^ ((node >> 4) & 15u) : node;
+#else
+  return node;
+#endif
+}
 template <int REC>
 EKM_HD HeapNode heap_read(const float* __restrict__ tab, unsigned node) {
   HeapNode r;
+  if (REC == 4) node = heap_slot(node);
 #if defined(__HIP_DEVICE_COMPILE__)
   const char* __restrict__ base = reinterpret_cast<const char*>(tab);
   if (REC == 4) {
@@ -951,6 +969,7 @@ EKM_HD HeapNode heap_read(const float* __restrict__ tab, unsigned node) {
 }
 template <int REC>
 EKM_HD float heap_es(const float* __restrict__ tab, unsigned node) {
+  if (REC == 4) node = heap_slot(node);
   return tab[(REC == 4 ? 4 : 2) * node];
 }
 
@@ -981,10 +1000,11 @@ EKM_HD void bisect_heap_fill(float* __restrict__ tab, int i) {
     }
   }
   if (REC == 4) {
-    tab[4 * i] = es;
-    tab[4 * i + 1] = a;
-    tab[4 * i + EKM_HEAP_L_SLOT] = L;
-    tab[4 * i + (5 - EKM_HEAP_L_SLOT)] = EKM_HEAP_BAND_SLOT ? float(kHeapTau1) * __builtin_fabsf(a) : t;
+    const int s = (int)heap_slot((unsigned)i);  // (a permutation within each aligned group of 16 records)
+    tab[4 * s] = es;
+    tab[4 * s + 1] = a;
+    tab[4 * s + EKM_HEAP_L_SLOT] = L;
+    tab[4 * s + (5 - EKM_HEAP_L_SLOT)] = EKM_HEAP_BAND_SLOT ? float(kHeapTau1) * __builtin_fabsf(a) : t;
   } else {
     tab[2 * i] = es;
     tab[2 * i + 1] = a;

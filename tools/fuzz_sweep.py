@@ -43,6 +43,25 @@ def twin_sweep(a):
     print(f"fuzz sweep (host twin): {a.seeds} seeds x {a.n} points x {2 * len(_fuzz.CASES + _fuzz.CASES_MORE)} cases: no real miss, {time.time() - t0:.0f} s")
 
 
+def ill_conditioned_sweep(a):
+    """README "Parity" names two regions it excepts; this prints, per seed, how often the kernels (or the host twin) miss the
+    fp32 reference there against how often the reference's own fp32 run misses its fp64 run."""
+    if a.twin:
+        import _hosttwin as twin
+
+        run = lambda func, ins, kw: twin.by_reference_name(func, ins, dict(kw), np.float32)  # noqa: E731
+    else:
+        import ekm_hip
+
+        run = lambda func, ins, kw: getattr(ekm_hip.thermo, func)(*ins, **kw)  # noqa: E731
+    for s in range(a.seeds):
+        seed = a.first_seed + 17 * s
+        for kind in sorted(_fuzz.ILL_CONDITIONED):
+            d = _fuzz.make_ill_conditioned(kind, n=a.n, seed=seed)
+            func, keys, kw = _fuzz.ILL_CONDITIONED[kind]
+            print(f"seed {seed} {_fuzz.judge_vs_reference_spread(kind, d, run(func, [d[k] for k in keys], kw))}", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=3)
@@ -52,8 +71,12 @@ def main():
                     "next to the search tree's node pressures, to p0 and to saturation; 2 = also theta_e next to the Davies-Jones "
                     "regime thresholds (then without the limits on how many points may need an explanation)")
     ap.add_argument("--twin", action="store_true", help="run the host twin instead of the GPU")
+    ap.add_argument("--ill-conditioned", action="store_true", help="the two regions of physical input where the reference's own fp32 and "
+                    "fp64 Newton runs disagree beyond 1e-4 (tests/_fuzz.py::ILL_CONDITIONED): ours against the reference's own spread")
     a = ap.parse_args()
     np.seterr(all="ignore")
+    if a.ill_conditioned:
+        return ill_conditioned_sweep(a)
     if a.twin:
         return twin_sweep(a)
     import ekm_hip

@@ -56,6 +56,10 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--nflat", type=int, default=-1, help="hybrid: leading pure pressure levels passed to the library (-1 = count them)")
     ap.add_argument("--skew", default="0", help="comma list: byte offset added to the k-th array's base (k*skew)")
+    ap.add_argument("--smooth", action="store_true",
+                    help="overwrite the generator's fields (N(0, 8 K) and U(1, 100 %) PER POINT: neighbouring lanes hundreds of search-tree "
+                         "leaves apart) with horizontally smooth ones of the same per-level ranges: T = T_std(p_k) + 8 K x a low-wavenumber "
+                         "pattern, RH and p likewise -- what an analysis field looks like to a wave (VERDICT r5 item 2d); fp32, p a field or levels")
     ap.add_argument("--params", default="", help="secondary parameters to sweep, e.g. hybrid_band_kb=512:4096:32768,"
                                                    "lev_per_wg=1:2 (ekm_set_tuning_param); the cross product is run")
     a = ap.parse_args()
@@ -83,6 +87,28 @@ def main():
     outs = bases[3:]
     chk(getattr(base, f'ekm_synth_fill_{a.dtype}')(dev, None, t, q, p, 0, n, INNER, a.levels, 20260313))
     chk(getattr(base, f'ekm_synth_levels_{a.dtype}')(dev, None, pl, a.levels))
+    if a.smooth:
+        import numpy as np
+
+        from oracle import synthetic
+        from oracle import thermo_oracle as orc
+
+        dt = np.float32 if a.dtype == "f32" else np.float64
+        nlat = 1800 if INNER == 1800 * 3600 else 1
+        y, x = np.meshgrid(np.linspace(0, 1, nlat, endpoint=False), np.linspace(0, 1, INNER // nlat, endpoint=False), indexing="ij")
+        pat = [(np.sin(2 * np.pi * (3 * x + k1 * y)) * np.cos(2 * np.pi * (2 * y + k2 * x))).ravel() for k1, k2 in ((1, 0.5), (2, 1.5), (0.5, 1))]
+        pl_host = synthetic.level_pressures(137)[np.linspace(0, 136, a.levels).round().astype(int)] if a.levels != 137 else synthetic.level_pressures(137)
+        for k in range(a.levels):
+            pk = pl_host[k] * (1.0 + 0.05 * pat[2]) if a.pmode == "field" else np.full(INNER, pl_host[k])
+            tk = np.clip(synthetic.standard_temperature(pk) + 8.0 * pat[0], 180.0, 330.0)
+            with np.errstate(all="ignore"):
+                qk = orc.specific_humidity_from_relative_humidity(tk, 50.5 + 49.5 * pat[1], pk)
+            qk = np.where(np.isnan(qk), 3e-6, np.minimum(qk, 0.04))
+            for ptr, arr in ((t, tk), (q, qk), (p, pk)):
+                h = np.ascontiguousarray(arr.astype(dt))
+                chk(base.ekm_h2d(dev, ptr + k * INNER * isz, h.ctypes.data, h.nbytes, None))
+            chk(base.ekm_sync(dev))
+        print(f"# --smooth: t, q, p overwritten with low-wavenumber fields ({a.levels} levels)", flush=True)
     ev0, ev1 = C.c_void_p(), C.c_void_p()
     chk(base.ekm_event_create(dev, C.byref(ev0)))
     chk(base.ekm_event_create(dev, C.byref(ev1)))
