@@ -22,7 +22,14 @@ for ln in open(sys.argv[1]):
         print("FAILED", d["failed"]); continue
     r, c = d["roofline"], d["config"]
     hbm = r.get("hbm_achieved_gbs", r["achieved"])
+    sets = ""
+    if r.get("kernel_ms_sets"):  # the same kernel on three independently allocated buffer sets (bench.py --buffer-sets)
+        f = [r["bytes_per_point"] * r["points_per_launch"] / (m * 1e-3) / 1e9 / 8000.0 for m in r["kernel_ms_sets"]]
+        sets = f"  sets hbm frac min/med/max {min(f):.3f}/{sorted(f)[len(f) // 2]:.3f}/{max(f):.3f}"
+    e2e = d.get("end_to_end")
+    sets += f"  e2e {e2e['call_ms']:.1f} ms {e2e['gbs']:.0f} GB/s" if e2e else ""
+    pts = d["parity"].get("points") if d["parity"] else None
     print(f"{c['workload'].split(' on ')[0][:44]:44s} {c['p_mode']:6s} {d['dtype']} {r['bytes_per_point']:3d} B/pt  {r['kernel_ms']:7.3f} ms  "
           f"{hbm:7.1f} GB/s  hbm frac {r.get('hbm_frac', r['frac']):.3f}  " + (f"valu frac {r['frac']:.3f}  " if r["bound"] == "valu" else "") + f"parity {d['parity']['ok'] if d['parity'] else None} "
-          f"maxrel {d['parity']['max_rel_err'] if d['parity'] else None}")
+          f"maxrel {d['parity']['max_rel_err'] if d['parity'] else None} on {pts} points" + sets)
 PY

@@ -10,7 +10,7 @@ fail=0
 for pm in field level; do
   i=0
   for set in "${SETS[@]}"; do
-    rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$O/pmc_${pm}_$i" -- python3 bench.py --workload wetbulb_bisect --pmode $pm --steps 3 --warmup 1 --no-cpu-baseline --traffic none --valu none --sustain 0 "$@" > "$O/out_${pm}_$i.txt" 2> "$O/err_${pm}_$i.txt"
+    rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$O/pmc_${pm}_$i" -- python3 bench.py --workload wetbulb_bisect --pmode $pm --steps 3 --warmup 1 --no-cpu-baseline --traffic none --valu none --sustain 0 --parity-slab-levels 0 --no-end-to-end --buffer-sets 1 "$@" > "$O/out_${pm}_$i.txt" 2> "$O/err_${pm}_$i.txt"
     rc=$?
     if [ $rc -ne 0 ]; then echo "pmc_bisect: pass $pm/$i ($set) FAILED rc=$rc"; tail -5 "$O/err_${pm}_$i.txt"; fail=1; fi
     i=$((i+1))

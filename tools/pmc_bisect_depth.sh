@@ -10,7 +10,7 @@ for d in 2 4 6 8 10 12; do
   if [ $d -eq 12 ]; then unset EKM_THERMO_LIB; else export EKM_THERMO_LIB=$GRAFT_REPO_ROOT/earthkit-meteo_amd/variants/d$d/libekm_thermo.so; fi
   i=0
   for set in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
-    rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$O/pmc_d${d}_$i" -- python3 bench.py --workload wetbulb_bisect --pmode field --steps 3 --warmup 1 --no-cpu-baseline --traffic none --valu none --sustain 0 --no-stream-ceiling > "$O/out_d${d}_$i.txt" 2> "$O/err_d${d}_$i.txt"
+    rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$O/pmc_d${d}_$i" -- python3 bench.py --workload wetbulb_bisect --pmode field --steps 3 --warmup 1 --no-cpu-baseline --traffic none --valu none --sustain 0 --no-stream-ceiling --parity-slab-levels 0 --no-end-to-end --buffer-sets 1 > "$O/out_d${d}_$i.txt" 2> "$O/err_d${d}_$i.txt"
     rc=$?
     if [ $rc -ne 0 ]; then echo "pmc_bisect_depth: pass d=$d/$i FAILED rc=$rc"; tail -5 "$O/err_d${d}_$i.txt"; fail=1; fi
     i=$((i+1))

@@ -13,7 +13,7 @@ for set in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" \
   i=$((i+1))
   for wl in geopotential hybrid_levels theta p3; do
     timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$O/pass${i}_$wl" -- python3 bench.py --workload $wl --steps 3 --warmup 1 \
-      --no-cpu-baseline --traffic none --valu none --sustain 0 > "$O/pass${i}_$wl.json" 2> "$O/pass${i}_$wl.err" || echo "pass $i $wl failed"
+      --no-cpu-baseline --traffic none --valu none --sustain 0 --parity-slab-levels 0 --no-end-to-end --buffer-sets 1 > "$O/pass${i}_$wl.json" 2> "$O/pass${i}_$wl.err" || echo "pass $i $wl failed"
   done
 done
 python3 - "$O" <<'PY'
