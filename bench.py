@@ -408,6 +408,20 @@ def main():
         lev0, lev1, col0, col1 = sh["lev0"], sh["lev1"], sh["col0"], sh["col1"]
         nlev_loc, ncol = lev1 - lev0, col1 - col0   # this shard's levels / columns
         seed = 20260313 + (dist.rank if args.scaling == "weak" else 0)
+        link_at_start = None
+        if dist.world == 1 and args.end_to_end and not os.environ.get("EKM_BENCH_NO_LINK_PROBE"):
+            # what a plain 207-MB host-to-device copy gets in THIS process before anything else has run (diagnostic for
+            # `end_to_end`: on the same box some processes get half the link's rate for every copy, from their first one on)
+            probe = np.ones(8 * INNER, np.float32)
+            rates = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                dprobe = DeviceArray.from_host(probe, dev)
+                _ffi.check(lib.ekm_sync(dev))
+                rates.append(probe.nbytes / (time.perf_counter() - t0) / 1e9)
+                dprobe.free()
+            link_at_start = round(max(rates), 1)
+            del probe
         t, q, p, plev, hyb = build_inputs(args, sh, dev, nlev, np_dtype, seed)
         outs = [DeviceArray.empty(shape, np_dtype, dev) for _ in range(nout)]
 
@@ -528,6 +542,8 @@ def main():
             sets = time_buffer_sets(args, sh, dev, nlev, np_dtype, seed, nout, entry, ints, my_ms)
         if args.end_to_end:
             e2e = end_to_end(args, t, q, p, plev, nlev, np_dtype)
+            if e2e is not None:
+                e2e["h2d_gbs_at_process_start"] = link_at_start
     # The streaming reference of THIS launch on THESE buffers (the sample above is on the host by now: the outputs are
     # overwritten): the same input fields read and the same output fields written by a kernel that computes nothing
     # (ekm_stream_mix: the map kernels' launch shape, one add per stream).  The same kernel is 5-10 % faster or slower from

@@ -584,12 +584,21 @@ _PINNED_OUT = os.environ.get("EKM_PINNED_RESULTS", "1") != "0"
 from .device import _pinned as _pinned_pool  # noqa: E402
 
 _PINNED_OUT_BYTES = int(os.environ.get("EKM_PINNED_RESULTS_BYTES", str(_pinned_pool.limit)))
+# Round 6, OPT-IN (EKM_DIRECT_RESULTS=1): results that live in pooled pinned memory are WRITTEN THERE BY THE KERNEL (pinned host
+# memory is mapped into the device's address space: the output pointers of the launch are the host blocks) instead of into
+# device blocks that a DMA engine then copies down; the kernel's stores cross PCIe as they are issued while the next slice's
+# uploads run on their DMA engine.  Same bits (tests/test_gpu_streaming.py).  Measured (profiles/r06_host_path_rate.txt, one
+# box, 8 / 32 levels, both directions together): the six-output pipeline 69.9 / 72.8 GB/s against 68.2 / 72.1 with downloads,
+# es-td-rh 74.8 / 80.9 against 80.3 / 88.5, theta 62.2 / 68.4 against 67.1 / 76.0 -- shader stores to host memory reach a
+# little less than a DMA engine does, so where as much goes up as comes down the downloads win: off by default.  One device
+# only (a block pinned through one device's context), compute dtype = result dtype.
+_DIRECT_OUT = os.environ.get("EKM_DIRECT_RESULTS", "0") == "1"
 
 
 class _Pending:
     """One submitted launch: device results (and the temporaries its operands live in) not yet collected."""
 
-    __slots__ = ("plan", "results", "temps", "host_out", "internal_out", "toucher", "stream", "keep")
+    __slots__ = ("plan", "results", "temps", "host_out", "internal_out", "toucher", "stream", "keep", "direct")
 
 
 def _reserved(nbytes, reserve_rows):
@@ -605,12 +614,14 @@ def _run_single(name, args, ints=(), eps=None, dtype=None, host_out=None, touche
     return _collect(_submit(name, args, ints, eps, dtype, host_out, toucher))
 
 
-def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=None, reserve_rows=None, uploaded=None):
+def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=None, reserve_rows=None, uploaded=None,
+            pinned_out=False):
     """Upload what lives on the host, launch, return without waiting for the kernel (the uploads themselves are
     synchronous copies on the current stream).  `reserve_rows` = (rows of this slice, rows of the longest slice):
     field-sized device blocks are reserved at the longest slice's size (streamed path).  `uploaded`: an event handle
     recorded on the stream behind the last upload and BEFORE the launch (the streamed path waits for a slice's uploads,
-    not for its kernel)."""
+    not for its kernel).  `pinned_out`: the caller's `host_out` arrays are pooled pinned memory -- the kernel may write
+    its results there directly (_DIRECT_OUT)."""
     ins, outs, int_names, has_eps = OPS[name]
     assert len(args) == len(ins) and len(ints) == len(int_names)
     plan = _Plan(args, dtype)
@@ -637,6 +648,8 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
             host_out = [pinned_empty(plan.shape, plan.dtype) for _ in outs]
             if any(h is None for h in host_out):
                 host_out = None
+            else:
+                pinned_out = True
         if host_out is None:
             host_out = [np.empty(plan.shape, plan.dtype) for _ in outs]
             toucher = _pretouch(host_out)
@@ -693,12 +706,15 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
         # .on(stream): an input last used on another stream makes this stream wait for that work (device-side)
         operands.append(_ffi.Operand(darr.on(stream), cls[0], 0, cls[1], cls[2]))
 
-    results = [DeviceArray.empty(plan.shape, plan.dtype, dev, capacity=_reserved(plan.n * plan.dtype.itemsize, reserve_rows))
-               for _ in outs]
+    # results straight into the caller's pinned host blocks (see _DIRECT_OUT), else into device blocks that are downloaded
+    direct = bool(_DIRECT_OUT and pinned_out and host_out is not None and not plan.on_device and plan.n and _capturing() is None
+                  and not _sharding() and all(h.dtype == plan.dtype and h.flags.c_contiguous and h.size == plan.n for h in host_out))
+    results = [] if direct else [
+        DeviceArray.empty(plan.shape, plan.dtype, dev, capacity=_reserved(plan.n * plan.dtype.itemsize, reserve_rows)) for _ in outs]
     cargs = [dev, stream] + [C.byref(o) for o in operands] + [int(v) for v in ints]
     if has_eps:
         cargs.append(float(eps))
-    cargs += [r.ptr for r in results] + [plan.n]
+    cargs += ([h.ctypes.data for h in host_out] if direct else [r.ptr for r in results]) + [plan.n]
     if uploaded is not None:
         _ffi.check(lib.ekm_event_record(dev, uploaded, stream))
     _ffi.check(fn(*cargs))
@@ -713,7 +729,7 @@ def _submit(name, args, ints=(), eps=None, dtype=None, host_out=None, toucher=No
             _recipes[key] = rec
     pend = _Pending()
     pend.plan, pend.results, pend.temps, pend.host_out = plan, results, temps, host_out
-    pend.internal_out, pend.toucher, pend.stream, pend.keep = internal_out, toucher, stream, keep
+    pend.internal_out, pend.toucher, pend.stream, pend.keep, pend.direct = internal_out, toucher, stream, keep, direct
     return pend
 
 
@@ -735,6 +751,17 @@ def _collect(pend, refile=None):
 
     if toucher is not None:
         toucher.join()
+    if pend.direct:  # the kernel wrote into the pinned host blocks: wait for IT (on the stream it runs on), nothing to copy
+        _ffi.check(_ffi.lib().ekm_stream_sync(plan.device, pend.stream))
+        pend.keep = None
+        for t in temps:
+            t.free()
+        host = []
+        for h in host_out:
+            if plan.out_dtype != plan.dtype and internal_out:
+                h = h.astype(plan.out_dtype)
+            host.append(h[()] if plan.all_scalar else h)
+        return tuple(host)
     host = []
     # the downloads of a call are queued back to back and waited for ONCE
     direct = [host_out is not None and host_out[k].dtype == plan.dtype and host_out[k].flags.c_contiguous for k in range(len(results))]

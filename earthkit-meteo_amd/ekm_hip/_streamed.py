@@ -222,7 +222,7 @@ def _run_streamed(name, args, ints, eps, dtype, devs):
                 # back exactly the blocks it released (same bucket) and the footprint stays lanes x slice, live + cached
                 ev = _uploaded_event(dev, k % depth)
                 pend = _submit(name, part, ints, eps, dtype, host_out=[o[lo:hi] for o in outs], reserve_rows=(hi - lo, most),
-                               uploaded=ev)
+                               uploaded=ev, pinned_out=pinned_outs and len(devs) == 1)
                 # ONE slice's uploads in flight: from pinned inputs they are asynchronous, and the uploads of several lanes
                 # queued at once share the link badly (P3 from pinned inputs: 60 GB/s against 77 with this wait).  The wait
                 # is for the UPLOADS (an event recorded behind the last one, before the launch), not for the slice's kernel:

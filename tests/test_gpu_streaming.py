@@ -38,6 +38,29 @@ def test_large_multi_output_numpy_call_is_bit_equal_to_the_device_path(ek):
             assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), f"rep {rep} output {k} differs"
 
 
+def test_kernels_writing_straight_into_pinned_results_give_the_same_bits(ek, monkeypatch):
+    """EKM_DIRECT_RESULTS=1 (round 6, opt-in): the output pointers of a launch are the pooled pinned host blocks, nothing is
+    downloaded.  The streamed call (>= 256 MB in), a single-launch call (the pool is used from 32 MiB of results) and a ragged
+    size through both -- the bits of the DeviceArray path."""
+    from ekm_hip import _engine
+
+    monkeypatch.setattr(_engine, "_DIRECT_OUT", True)
+    for nlev, npts, func in ((16, 1 << 21, "pipeline_full"), (16, (1 << 21) + 1028, "pipeline_svp_td_rh"), (3, (1 << 21) + 3, "pipeline_full")):
+        t, q, p = _fields(nlev, npts)
+        want = _device_path(ek, func, (t, q, p))
+        for rep in range(2):
+            got = getattr(ek.thermo, func)(t, q, p)
+            for k, (g, w) in enumerate(zip(got, want)):
+                assert g.dtype == w.dtype and g.shape == w.shape
+                assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), f"{func} {nlev}x{npts} rep {rep} output {k} differs"
+    # a level vector for the pressure and float64 inputs under a float32 override: still the same bits
+    t, q, p = _fields(16, 1 << 21)
+    pl = p[:, :1].copy()
+    want = _device_path(ek, "wet_bulb_temperature_from_specific_humidity", (t, q, pl), ept_method="ifs", t_method="bisect")
+    got = ek.thermo.wet_bulb_temperature_from_specific_humidity(t, q, pl, ept_method="ifs", t_method="bisect")
+    assert np.array_equal(got.view(np.uint32), want[0].view(np.uint32))
+
+
 def test_converted_operands_share_the_slice_pipeline(ek):
     """float64 inputs with a float32 override are converted copies: they travel with the other operands of a slice, rows
     of 8 MiB + 4112 B put the slice boundaries off the page grid, and the results are the bits of the device path."""
