@@ -536,12 +536,29 @@ def main():
     smp = None if args.dry_run else sample_shard(args, t, q, p, plev, outs, sh, nlev, np_dtype, hyb)
     slab, e2e, sets = None, None, None
     if not args.dry_run and dist.world == 1:
+        # the additional legs must never cost the run its line: a failure is reported in its place (and makes parity.ok false
+        # where it is the slab census that failed)
+        def leg(what, f, *a):
+            try:
+                return f(*a)
+            except Exception as exc:  # noqa: BLE001
+                import traceback
+
+                traceback.print_exc(file=sys.stderr)
+                return {"failed": f"{what}: {type(exc).__name__}: {exc}"}
+
         if args.parity_slab_levels > 0:
-            slab = slab_parity(args, t, q, p, plev, outs, nlev, np_dtype)
+            slab = leg("slab_parity", slab_parity, args, t, q, p, plev, outs, nlev, np_dtype)
+            if "failed" in slab:
+                slab["ok"] = False
+                slab["points"] = 0
         if args.buffer_sets > 1 and args.workload not in COLUMN_WORKLOADS:
-            sets = time_buffer_sets(args, sh, dev, nlev, np_dtype, seed, nout, entry, ints, my_ms)
+            sets = leg("time_buffer_sets", time_buffer_sets, args, sh, dev, nlev, np_dtype, seed, nout, entry, ints, my_ms)
+            if "failed" in sets:
+                print("bench.py: " + sets["failed"], file=sys.stderr)
+                sets = None
         if args.end_to_end:
-            e2e = end_to_end(args, t, q, p, plev, nlev, np_dtype)
+            e2e = leg("end_to_end", end_to_end, args, t, q, p, plev, nlev, np_dtype)
             if e2e is not None:
                 e2e["h2d_gbs_at_process_start"] = link_at_start
     # The streaming reference of THIS launch on THESE buffers (the sample above is on the host by now: the outputs are
