@@ -552,15 +552,18 @@ def main():
             if "failed" in slab:
                 slab["ok"] = False
                 slab["points"] = 0
+        # (end_to_end BEFORE the buffer sets: returning tens of GB of device memory to the driver -- what the sets do when they are
+        # freed, beyond what the block cache keeps -- is followed by a period in which every host<->device copy runs at half
+        # rate, in this process and in the next one on the device: profiles/r06_host_path_rate.txt)
+        if args.end_to_end:
+            e2e = leg("end_to_end", end_to_end, args, t, q, p, plev, nlev, np_dtype)
+            if e2e is not None:
+                e2e["h2d_gbs_at_process_start"] = link_at_start
         if args.buffer_sets > 1 and args.workload not in COLUMN_WORKLOADS:
             sets = leg("time_buffer_sets", time_buffer_sets, args, sh, dev, nlev, np_dtype, seed, nout, entry, ints, my_ms)
             if "failed" in sets:
                 print("bench.py: " + sets["failed"], file=sys.stderr)
                 sets = None
-        if args.end_to_end:
-            e2e = leg("end_to_end", end_to_end, args, t, q, p, plev, nlev, np_dtype)
-            if e2e is not None:
-                e2e["h2d_gbs_at_process_start"] = link_at_start
     # The streaming reference of THIS launch on THESE buffers (the sample above is on the host by now: the outputs are
     # overwritten): the same input fields read and the same output fields written by a kernel that computes nothing
     # (ekm_stream_mix: the map kernels' launch shape, one add per stream).  The same kernel is 5-10 % faster or slower from
