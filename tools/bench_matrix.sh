@@ -3,9 +3,10 @@
 #   tools/bench_matrix.sh <out.jsonl> [extra bench.py args...]
 OUT=${1:?out.jsonl}; shift
 : > "$OUT"
+sleep_between=${EKM_MATRIX_SLEEP:-6}  # seconds between runs: a bench process returns 40-100 GB of device memory at exit, and while the driver clears it every host<->device copy on the GPU runs at half rate (profiles/r06_host_path_rate.txt)
 for wl in full p3 wetbulb wetbulb_bisect theta rh ept; do
   for pm in field level hybrid; do
-    timeout -k 10 120 python3 bench.py --workload $wl --pmode $pm --steps 20 --warmup 5 --no-cpu-baseline --traffic file --valu file --sustain 0 "$@" >> "$OUT" 2>> "$OUT.err" || echo "{\"failed\": \"$wl $pm\"}" >> "$OUT"
+    timeout -k 10 120 python3 bench.py --workload $wl --pmode $pm --steps 20 --warmup 5 --no-cpu-baseline --traffic file --valu file --sustain 0 "$@" >> "$OUT" 2>> "$OUT.err" || echo "{\"failed\": \"$wl $pm\"}" >> "$OUT"; sleep $sleep_between
   done
 done
 for wl in wetbulb_bisect_bolton35 wetbulb_bisect_bolton39; do
