@@ -232,8 +232,28 @@ struct BisectOp : BisectTable<METHOD> {
     T te[V], lte[V], p[V], kl[V], out[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) Derived::template prep<T, true>(x[j], te[j], lte[j], p[j], kl[j]);
-    if constexpr (sizeof(T) == 4)
+    if constexpr (sizeof(T) == 4) {
+#if defined(EKM_WALK_SPLIT)  // A/B (round 6, NEGATIVE: 3.08 -> 3.17 ms): the four points of a lane's chunk as two walks of two -- 57
+      // registers instead of 64 and no recomputed thr0, but two LDS reads in flight per wave instead of four (profiles/r06_tree_walk.txt)
+      if constexpr (V == 4) {
+        T l2[2], t2[2], p2[2], k2[2], o2[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            l2[j] = lte[2 * h + j];
+            t2[j] = te[2 * h + j];
+            p2[j] = p[2 * h + j];
+            k2[j] = kl[2 * h + j];
+          }
+          t_on_ma_bisect_heap<METHOD, 2>(l2, t2, p2, k2, tab, o2, all_exact);
+          out[2 * h] = o2[0];
+          out[2 * h + 1] = o2[1];
+        }
+      } else
+#endif
       t_on_ma_bisect_heap<METHOD, V>(lte, te, p, kl, tab, out, all_exact);
+    }
     else  // double / fd64: sign tests in fp32 on the tree behind the fp64 lattice table, ambiguous steps in T
       t_on_ma_bisect_heap64<METHOD, T, V>(lte, te, p, kl, reinterpret_cast<const float*>(tab + kBisectLattice), tab, out, all_exact);
 #pragma unroll
