@@ -279,6 +279,44 @@ __global__ __launch_bounds__((OpThreads<Op, T>::value), (OpThreads<Op, T>::field
   const unsigned long long nvec = a.n / V;
   const unsigned long long base = (unsigned long long)blockIdx.x * tiles * NT + threadIdx.x;
 
+#if defined(EKM_WALK_V8)
+  // A/B (round 6, NEGATIVE: 3.10 -> 3.35 ms): the fp32 IFS tree walk with EIGHT points per lane walking together (two tiles per
+  // trip), 512-thread workgroups at 104 registers = 4 waves per SIMD: the same 32 points per SIMD in flight as 8 waves x 4
+  // points, twice the independent LDS reads per wave and half the per-wave scalar work per point -- and 8 % slower; two
+  // points per walk (ops.hpp: EKM_WALK_SPLIT) is 3 % slower too: 8 waves x 4 points is the optimum (profiles/r06_tree_walk.txt)
+  if constexpr (OpThreads<Op, T>::wide && UNROLL == 1 && NOUT == 1) {
+    for (unsigned k = 0; k < tiles; k += 2) {
+      const unsigned long long v0 = base + (unsigned long long)k * NT, v1 = v0 + NT;
+      if (v0 < nvec) {
+        const bool ok1 = (k + 1 < tiles) && v1 < nvec;
+        const unsigned long long w1 = ok1 ? v1 : v0;
+        Vec xa[NIN], xb[NIN];
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) xa[i] = ld_stream<T>(a.in[i] + v0 * V);
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) xb[i] = ld_stream<T>(a.in[i] + w1 * V);
+        T x[2 * V][NIN], y[2 * V][NOUT];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+#pragma unroll
+          for (int i = 0; i < NIN; ++i) {
+            x[j][i] = xa[i][j];
+            x[V + j][i] = xb[i][j];
+          }
+        }
+        OpTable<Op>::template apply_v<T, 2 * V>(x, y, a.rp, op_tab, (a.switches & 2) != 0);
+        Vec ya, yb;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          ya[j] = y[j][0];
+          yb[j] = y[V + j][0];
+        }
+        st_stream<T>(a.out[0] + v0 * V, ya);
+        if (ok1) st_stream<T>(a.out[0] + v1 * V, yb);
+      }
+    }
+  } else
+#endif
   for (unsigned k = 0; k < tiles; k += UNROLL) {
     const unsigned long long v0 = base + (unsigned long long)k * NT;
     Vec xin[UNROLL][NIN];

@@ -526,9 +526,17 @@ struct OpThreads {
   static constexpr bool tree = OpTable<Op>::elems > 0 && OpTable<Op>::vectorized;
   // the fp32 IFS walk with 16-B records: 64 KiB, two 1024-thread workgroups = eight waves per SIMD (<= 64 registers)
   static constexpr bool wide = tree && sizeof(T) == 4 && OpTreeMethod<Op>::value == EPT_IFS && heap_rec<EPT_IFS, float>() == 4;
+#if defined(EKM_WALK_V8)
+  static constexpr int value = wide ? 512 : tree ? EKM_TREE_THREADS : EKM_THREADS_DEFAULT;  // A/B: map_kernel.hpp::map_fields
+#else
   static constexpr int value = wide ? 1024 : tree ? EKM_TREE_THREADS : EKM_THREADS_DEFAULT;
+#endif
   // else fp32: 48 KiB, three workgroups = six waves per SIMD (<= 80 registers); fp64: 80 KiB, two workgroups = four waves
+#if defined(EKM_WALK_V8)
+  static constexpr int field_waves = wide ? 4 : tree ? (sizeof(T) == 4 ? EKM_TREE_WAVES : 4) : EKM_WAVES_PER_EU;
+#else
   static constexpr int field_waves = wide ? 8 : tree ? (sizeof(T) == 4 ? EKM_TREE_WAVES : 4) : EKM_WAVES_PER_EU;
+#endif
 };
 
 // Waves per SIMD a kernel of this op should be compiled for (launch bounds: caps the register allocation).
