@@ -1567,7 +1567,10 @@ EKM_HD T t_on_ma_newton_ifs_core(T lte, T p, T dinv, const TeFn& te_fn, const Pp
   // NaN c_te, i.e. a NaN lte: the reference then carries ept through one Newton step against a NaN c_te -- NaN.
   T tw = lte;
   if (EKM_ANY(R.r1)) {
-    const T te = te_fn();
+    // (lanes outside regime 1 do not use this guess: they take a temperature far below TI, so that a wave whose regime-1
+    // lanes are all at or below TI -- regime 1 is te < 244-260 K, ice for most of them -- evaluates ONE phase of es instead of
+    // both phases and the blend because of the warmer lanes beside them; the regime-1 lanes' own values are unchanged)
+    const T te = R.r1 ? te_fn() : T(k::TI - 50.0);
     T es, des;
     es_slope_mixed<true>(te, es, des);
     // te - t0 - A*ws/(1 + A*ws*des/es) with ws = eps*es/v, v = p - es (thermo.py:1116-1119): the two divisions are one,
