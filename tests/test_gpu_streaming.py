@@ -396,6 +396,15 @@ def test_bench_measures_its_hbm_traffic_in_the_run(ek):
     assert 100 < c["SQ_INSTS_VALU"] < 300 and 10 < c["SQ_INSTS_VALU_TRANS_F32"] < 40, c
     assert 0.2 < roof["valu_frac"] < roof["frac"] < 1.0  # the six-output pipeline is HBM-bound: the HBM fraction is the larger
     assert d["sustained"]["launches"] >= 3 and d["sustained"]["seconds"] >= 1.9 and 0.3 < d["sustained"]["frac"] < 1.0
+    # round 6: parity on EVERY point of the 8-level slab of the timed arrays with the wet-bulb's regime census,
+    # the kernel on three independently allocated buffer sets, and the PCIe-inclusive figure beside `value`
+    p = d["parity"]
+    assert p["points"] == 8 * 1800 * 3600 and p["over"] == 0 and p["nan_mismatch"] == 0 and p["excluded_points"] == 0, p
+    assert p["regime_flips"] >= 0 and p["regime_boundary_points_1e5"] > 0 and p["tw_over_unexplained"] == 0 and p["windows"]["ok"], p
+    assert len(roof["frac_sets"]) == 3 and roof["frac_min"] <= roof["frac_median"] <= roof["frac_max"] and roof["frac_sets"][0] == roof["frac"], roof
+    e = d["end_to_end"]
+    assert e["points"] == 8 * 1800 * 3600 and e["arrays_in"] == 3 and e["arrays_out"] == 6, e
+    assert 0 < e["kernel_ms"] < e["h2d_ms"] < e["d2h_ms"] and e["call_ms"] < e["phases_sum_ms"] * 1.5 and 10 < e["gbs"] < 120, e
 
 
 def test_concurrent_calls_from_several_threads(ek):
