@@ -1671,17 +1671,23 @@ EKM_HD T t_on_ma_newton(T e, T p, Tie& tie) {
   // initial guess (deg C); later regimes overwrite earlier ones (thermo.py:1114-1128)
   T tw = e;
   {
-    T es, des;
-    es_slope_mixed(te, es, des);
-    const T ws = w_from_e(es, p, T(k::eps_default));
-    const T aw = A * ws;
-    T dr = m_div(aw * des, es);  // A*ws*des/es (thermo.py:1119): 0/0 where the reference's es is zero, else nothing beside 1
-    if (!(es > es_negligible<T>()) && es == es) dr = te < es_zero_below<T>() ? nan_v<T>() : T(0);
-    const T g1 = te - t0 - m_div(aw, T(1) + dr);
-    const T k1 = poly2(pp, -53.737, 137.81, -38.5);
-    const T k2 = poly2(pp, -0.384, 56.831, -4.392);
     const TeFromEpt<T> exact{e, p};
     const Regime R = davies_regime(c_te, c_te * (T(0.1859e-5) * p + T(0.6512)), p, exact, tie);
+    T g1 = te;  // (only ever used by regime-1 lanes)
+    if (EKM_ANY(R.r1)) {
+      // lanes outside regime 1 do not use this guess: they take a temperature far below TI, so that they do not make a wave
+      // of cold regime-1 lanes evaluate both phases of es (as in t_on_ma_newton_ifs_core; the regime-1 lanes' values are unchanged)
+      const T te1 = R.r1 ? te : T(k::TI - 50.0);
+      T es, des;
+      es_slope_mixed(te1, es, des);
+      const T ws = w_from_e(es, p, T(k::eps_default));
+      const T aw = A * ws;
+      T dr = m_div(aw * des, es);  // A*ws*des/es (thermo.py:1119): 0/0 where the reference's es is zero, else nothing beside 1
+      if (!(es > es_negligible<T>()) && es == es) dr = te1 < es_zero_below<T>() ? nan_v<T>() : T(0);
+      g1 = te1 - t0 - m_div(aw, T(1) + dr);
+    }
+    const T k1 = poly2(pp, -53.737, 137.81, -38.5);
+    const T k2 = poly2(pp, -0.384, 56.831, -4.392);
     if (R.r1) tw = g1;
     if (R.r2) tw = k1 - k2 * c_te;
     if (R.r3) tw = (k1 - T(1.21)) - (k2 - T(1.21)) * c_te;

@@ -25,6 +25,8 @@ W = {  # workload: entry, operands, ints, nout, bytes/pt (field p)
     "wetbulb_bisect_bolton35": ("wet_bulb_temperature_from_specific_humidity", "tqp", (1, 0), 1, 16),
     "wetbulb_bisect_bolton39": ("wet_bulb_temperature_from_specific_humidity", "tqp", (2, 0), 1, 16),
     "wetbulb_td": ("wet_bulb_temperature_from_dewpoint", "tqp", (0, 1), 1, 16),
+    "wetbulb_bolton35": ("wet_bulb_temperature_from_specific_humidity", "tqp", (1, 1), 1, 16),
+    "wetbulb_bolton39": ("wet_bulb_temperature_from_specific_humidity", "tqp", (2, 1), 1, 16),
     "t_on_ma_bisect": ("temperature_on_moist_adiabat", "tp", (0, 0), 1, 12),
     "rh": ("relative_humidity_from_specific_humidity", "tqp", (), 1, 16),
     "ept": ("ept_from_specific_humidity", "tqp", (0,), 1, 16),
